@@ -1,0 +1,125 @@
+/*
+ * mi355attn.h - C ABI of libmi355attn.so: the MI355X (gfx950) attention hot path of Mini-SGLang.
+ *
+ * The reference (CrazyDave999/Mini-SGLang) has no native code and no FFI: this path is reached
+ * through a Python operator interface (an attention-backend object).  Each entry point below names
+ * the reference routine it replaces (paths relative to the reference checkout).  The Python class
+ * that a maintainer plugs in at engine/model_runner.py:90-91 is mi355_attn.MI355AttnBackend, which
+ * binds these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - strides are in ELEMENTS of the pointed-to type;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *     no entry point synchronises, allocates or frees;
+ *   - return value: M355_OK (0) or a negative M355_ERR_* code; nothing throws or exits;
+ *   - index dtypes are the reference's: page_table int32 (memory/page_manager.py:22-24);
+ *     page_table_ids / seq_lens / prefix_lens / positions / out_cache_loc int64
+ *     (engine/batch.py:258-273, 299-317).
+ */
+#ifndef MI355ATTN_H
+#define MI355ATTN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M355_VERSION 100 /* 0.1.0 */
+
+enum {
+    M355_OK = 0,
+    M355_ERR_INVALID_ARG = -1, /* null pointer, negative size, misaligned pointer/stride        */
+    M355_ERR_UNSUPPORTED = -2, /* head_dim / group size / dtype this build has no kernel for    */
+    M355_ERR_WORKSPACE = -3,   /* workspace missing or smaller than m355_decode_workspace_bytes */
+    M355_ERR_LAUNCH = -4       /* hipGetLastError() after the launch was not hipSuccess         */
+};
+
+enum { M355_DTYPE_BF16 = 0, M355_DTYPE_F16 = 1, M355_DTYPE_F32 = 2 };
+
+int m355_version(void);
+const char *m355_strerror(int code);
+
+/* KV slot write.  Replaces KVCache.write_kv (memory/kvcache.py:69-79):
+ *     k_pool[loc[t]] = k_src[t];  v_pool[loc[t]] = v_src[t]          for t in [0, T)
+ * Pools are [S, Hkv, D] contiguous.  k_src / v_src are [T, Hkv*D] with a row stride (they are
+ * views of the packed qkv projection, models/llama.py:133-134), inner stride 1, 16-byte aligned
+ * rows.  Pure byte copy, bit-exact; negative slots wrap like torch indexing, out-of-range slots
+ * are skipped.  dtype selects the element size only (bf16/f16: 2 bytes, f32: 4 bytes). */
+int m355_kv_store(void *k_pool, void *v_pool, const void *k_src, const void *v_src,
+                  int64_t k_row_stride, int64_t v_row_stride, const int64_t *loc, int32_t T,
+                  int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void *stream);
+
+/* Slot index math.  Replaces the indexing expression at engine/batch.py:315-317 and :341-343:
+ *     out[i] = (int64) page_table[row_of_token[i], positions[i] / page_size] * page_size
+ *              + positions[i] % page_size                              for i in [0, n) */
+int m355_out_cache_loc(const int32_t *page_table, int64_t pt_row_stride, const int64_t *row_of_token,
+                       const int64_t *positions, int32_t page_size, int64_t n, int64_t *out,
+                       void *stream);
+
+/* Prefill metadata in one launch.  Replaces the per-request loop of Batch.prepare_for_prefill
+ * (engine/batch.py:280-317) once the host has chosen rows and pages:
+ *   plan (int32, device) = for each request r in [0, B): {row, prefix_len, seq_len, page_off}
+ *   pages (int32, device) = concatenation over requests of cat(prefix_ppns, new_pages); request r
+ *                           owns pages[page_off_r : page_off_r + ceil(seq_len_r / page_size)]
+ *   cu_q (int32, device, [B+1]) = exclusive prefix sum of (seq_len - prefix_len)
+ * Effects: page_table[row_r, 0:npages_r] = its pages (PageManager.write_ppns_prefill,
+ * memory/page_manager.py:45-46); positions[cu_q[r] + j] = prefix_len_r + j;
+ * row_of_token[...] = row_r; out_cache_loc[...] as above.  All outputs int64. */
+int m355_prefill_prepare(int32_t *page_table, int64_t pt_row_stride, const int32_t *plan,
+                         const int32_t *pages, const int32_t *cu_q, int32_t B, int32_t page_size,
+                         int64_t *positions, int64_t *row_of_token, int64_t *out_cache_loc,
+                         void *stream);
+
+/* Decode metadata in one launch.  Replaces Batch.prepare_for_decode (engine/batch.py:319-343):
+ *     seq_lens_out[b] = seq_lens_in[b] + 1 (the two may alias); positions[b] = seq_lens_out[b] - 1;
+ *     if new_pages[b] >= 0: page_table[rows[b], positions[b] / page_size] = new_pages[b]
+ *     out_cache_loc[b] = page_table[rows[b], positions[b] / page_size] * page_size + positions[b] % page_size
+ * new_pages[b] is the page the host allocator popped for request b, or -1 when the new token
+ * still fits its last page (memory/kvcache.py:49-56). */
+int m355_decode_prepare(int32_t *page_table, int64_t pt_row_stride, const int64_t *rows,
+                        const int64_t *seq_lens_in, int64_t *seq_lens_out, const int32_t *new_pages,
+                        int32_t B, int32_t page_size, int64_t *positions, int64_t *out_cache_loc,
+                        void *stream);
+
+/* Decode attention over the paged KV pools.  Replaces TorchNativeAttnBackend.forward_decode /
+ * _run_sdpa_forward_decode (layers/attention_backends/torch_native_backend.py:121-193, 237-276)
+ * minus the KV write (call m355_kv_store first on the same stream):
+ *     out[b, h, :] = softmax(q[b, h, :] . K_b[:, h / (Hq/Hkv), :]^T * scale) V_b[:, h / (Hq/Hkv), :]
+ * over ALL seq_lens[b] cached tokens of request b, token p living in slot
+ * page_table[page_table_ids[b], p / page_size] * page_size + p % page_size.
+ * q / out: [B, Hq*D] with row strides; pools [S, Hkv, D].  The reference always uses
+ * scale = D^-0.5 (SDPA default); it is an argument here so the caller states it.
+ * Long sequences are split into chunks of `chunk_tokens` (0 = choose from B, Hkv and
+ * max_seq_len_hint); partial results go through `workspace` (fp32) and a merge kernel.
+ * max_seq_len_hint must be >= max(seq_lens); it only sizes the grid. */
+int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t D, int32_t max_seq_len_hint,
+                                    int32_t chunk_tokens);
+int m355_decode_attn(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
+                     const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
+                     const int64_t *seq_lens, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                     int32_t Hkv, int32_t D, int32_t page_size, float scale, int32_t max_seq_len_hint,
+                     int32_t chunk_tokens, void *workspace, int64_t workspace_bytes, int32_t dtype,
+                     void *stream);
+
+/* Ragged prefill ("extend") attention over cached prefixes.  Replaces
+ * TorchNativeAttnBackend.forward_extend / _run_sdpa_forward_extend
+ * (torch_native_backend.py:25-119, 195-235) minus the KV write: packed query row cu_q[b] + j is
+ * the token at absolute position prefix_lens[b] + j of request b and attends cached tokens
+ * 0 .. prefix_lens[b] + j (its own K/V included - they are read back from the pool).
+ * cu_q: int32 [B+1] exclusive prefix sum of (seq_lens - prefix_lens); T = cu_q[B];
+ * max_extend_len >= max(seq_lens - prefix_lens) and max_seq_len_hint >= max(seq_lens) size the grid.
+ * workspace: fp32 scratch of m355_prefill_workspace_bytes(...) bytes (may be NULL when that is 0). */
+int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D, int32_t max_seq_len_hint);
+int m355_prefill_attn(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
+                      const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
+                      const int64_t *seq_lens, const int64_t *prefix_lens, const int32_t *cu_q,
+                      void *out, int64_t o_row_stride, int32_t B, int32_t T, int32_t max_extend_len,
+                      int32_t max_seq_len_hint, int32_t Hq, int32_t Hkv, int32_t D, int32_t page_size,
+                      float scale, void *workspace, int64_t workspace_bytes, int32_t dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355ATTN_H */

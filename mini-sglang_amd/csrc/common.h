@@ -1,0 +1,59 @@
+// Shared device helpers for libmi355attn (gfx950 only: 64-lane waves, v_dot2c_f32_bf16, GFX9 DPP).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi355attn.h"
+
+namespace m355 {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWave = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kNegBig = -1.0e30f;   // finite stand-in for -inf: (m_old - m_new) never makes a NaN
+
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// acc += a.lo*b.lo + a.hi*b.hi with bf16 pairs packed in a dword (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// f32 -> bf16 round-to-nearest-even through the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
+// x + (x from the lane selected by a GFX9 DPP control); fuses into v_add_f32_dpp
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true);
+    return x + __builtin_bit_cast(float, r);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <- lane 7-i within each 8
+constexpr int kDppMirror = 0x140;     // lane i <- lane 15-i within each 16
+
+// all-reduce (sum) over aligned groups of LANES consecutive lanes, LANES in {8, 16}
+template <int LANES>
+__device__ __forceinline__ float group_sum(float x) {
+    x = dpp_add<kDppXor1>(x);
+    x = dpp_add<kDppXor2>(x);
+    x = dpp_add<kDppHalfMirror>(x);
+    if constexpr (LANES == 16) x = dpp_add<kDppMirror>(x);
+    return x;
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? M355_OK : M355_ERR_LAUNCH; }
+
+}  // namespace m355

@@ -1,0 +1,14 @@
+"""mi355_attn - MI355X-native attention backend, KV-store write and page-table metadata for Mini-SGLang.
+
+Product code.  Needs libmi355attn.so (mini-sglang_amd/lib/, built by `make -C mini-sglang_amd/csrc`); there
+is no CPU or torch fallback for any device operation.
+"""
+from .attention import Attention
+from .backend import MI355AttnBackend
+from .batch import Batch, Mode, Req, SamplingParams
+from .kvcache import KVCache
+from .page_manager import PageManager
+from .radix_cache import PagedRadixCache
+
+__all__ = ["Attention", "MI355AttnBackend", "Batch", "Mode", "Req", "SamplingParams", "KVCache", "PageManager",
+           "PagedRadixCache"]

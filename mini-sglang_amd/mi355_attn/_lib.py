@@ -1,0 +1,88 @@
+"""ctypes binding of libmi355attn.so (declarations: include/mi355attn.h).
+
+There is no CPU fallback: a missing library, a missing symbol or a non-zero return code raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmi355attn.so")
+
+DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
+
+# name -> (restype, argtypes); must list every symbol include/mi355attn.h declares
+SIGNATURES = {
+    "m355_version": (c_int32, []),
+    "m355_strerror": (c_char_p, [c_int32]),
+    "m355_kv_store": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
+                                c_int32, c_int32, c_int64, c_int32, c_void_p]),
+    "m355_out_cache_loc": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "m355_prefill_prepare": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "m355_decode_prepare": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                      c_void_p, c_void_p, c_void_p]),
+    "m355_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "m355_decode_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
+                                   c_int32, c_void_p, c_int64, c_int32, c_void_p]),
+    "m355_prefill_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "m355_prefill_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_int32,
+                                    c_void_p]),
+}
+
+_lib = None
+
+
+class MI355AttnError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise if it or any declared symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MI355AttnError(
+            f"{LIB_PATH} not found: build it with `make -C mini-sglang_amd/csrc` (or __graft_entry__.build()); "
+            "this backend has no fallback path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MI355AttnError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().m355_strerror(code).decode()
+        raise MI355AttnError(f"{what} failed: {msg} (code {code})")
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+    try:
+        return {torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16, torch.float32: DTYPE_F32}[torch_dtype]
+    except KeyError:
+        raise MI355AttnError(f"unsupported dtype {torch_dtype}") from None
+
+
+def require_cuda(t, name: str):
+    if not t.is_cuda:
+        raise MI355AttnError(f"{name} must live on the GPU (got {t.device}); libmi355attn has no CPU path")
+    return t
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,121 @@
+"""MI355AttnBackend: the attention backend of Mini-SGLang rebuilt on hand-written HIP kernels.
+
+Drop-in for the object constructed at reference engine/model_runner.py:90-91.  Same interface as the two
+reference backends (layers/attention_backends/torch_native_backend.py:15-276 and
+flash_attention_backend.py:44-151):
+
+    backend = MI355AttnBackend(model_runner)
+    backend.init_forward_metadata(batch)                  # once per forward
+    o = backend.forward(q, k, v, layer, batch)            # once per layer; also forward_extend / forward_decode
+
+It works with this package's Batch (host mirrors of the lengths ride along, so no device sync happens) and
+with the reference's own Batch (then lengths are read back once per forward, as its FA3 backend does).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class ForwardMetadata:
+    """Built once per forward (the counterpart of FlashAttentionMetaData, flash_attention_backend.py:22-41)."""
+    decode: bool
+    max_seq_len: int
+    max_extend_len: int = 1
+    chunk_tokens: int = 0
+    cu_q: Optional[torch.Tensor] = None            # int32 [B+1], prefill only
+    workspace: Optional[torch.Tensor] = None
+
+
+def pick_decode_chunk(total_tokens: int, num_kv_heads: int) -> int:
+    """Tokens per wave for decode.  One wave streams one (request, kv head, chunk); aim for ~8 waves on each
+    of the 256 CUs, keep chunks >= 128 tokens (partials cost ~G/chunk extra traffic) and <= 1024 (LDS page
+    staging).  Uses the exact token total, which the host knows."""
+    want_items = 2048
+    chunk = 1024
+    while chunk > 128 and (total_tokens // chunk + 1) * num_kv_heads < want_items:
+        chunk //= 2
+    if (total_tokens // chunk + 1) * num_kv_heads < 512:
+        chunk = 64
+    return chunk
+
+
+class MI355AttnBackend:
+    def __init__(self, model_runner):
+        self.device = model_runner.device
+        self.page_size = model_runner.page_size
+        self.forward_metadata: Optional[ForwardMetadata] = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._num_kv_heads_hint = getattr(getattr(model_runner, "kvcache", None), "head_num", None)
+
+    # ---- metadata -------------------------------------------------------------------------------
+    def _ws(self, nbytes: int, device) -> Optional[torch.Tensor]:
+        if nbytes == 0:
+            return None
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
+        return self._workspace
+
+    def init_forward_metadata(self, batch) -> None:
+        lens = getattr(batch, "seq_lens_host", None)
+        if lens is None:
+            lens = [int(x) for x in batch.seq_lens.tolist()]          # one sync, like flash_attention_backend.py:60
+        if batch.mode.is_decode():
+            hkv = self._num_kv_heads_hint or batch.kvcache.head_num
+            self.forward_metadata = ForwardMetadata(decode=True, max_seq_len=max(lens),
+                                                    chunk_tokens=pick_decode_chunk(sum(lens), hkv))
+            return
+        pre = getattr(batch, "prefix_lens_host", None)
+        if pre is None:
+            pre = [int(x) for x in batch.prefix_lens.tolist()]
+        cu_q = getattr(batch, "cu_q", None)
+        if cu_q is None:
+            ext = (batch.seq_lens - batch.prefix_lens).to(torch.int32)
+            cu_q = torch.nn.functional.pad(torch.cumsum(ext, 0, dtype=torch.int32), (1, 0))
+        self.forward_metadata = ForwardMetadata(decode=False, max_seq_len=max(lens),
+                                                max_extend_len=max(s - p for s, p in zip(lens, pre)), cu_q=cu_q)
+
+    # ---- per layer ------------------------------------------------------------------------------
+    def forward(self, q, k, v, layer, batch):
+        if batch.mode.is_decode():
+            return self.forward_decode(q, k, v, layer, batch)
+        return self.forward_extend(q, k, v, layer, batch)
+
+    def _store_kv(self, k, v, layer, batch):
+        if k is None:
+            return                                                     # torch_native_backend.py:203, :245
+        assert v is not None
+        k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
+        ops.kv_store(k_pool, v_pool, batch.out_cache_loc, k, v)        # replaces KVCache.write_kv
+
+    def forward_decode(self, q, k, v, layer, batch):
+        md = self.forward_metadata
+        if md is None or not md.decode:
+            self.init_forward_metadata(batch)
+            md = self.forward_metadata
+        self._store_kv(k, v, layer, batch)
+        k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
+        B = q.shape[0]
+        ws = self._ws(ops.decode_workspace_bytes(B, layer.num_heads, layer.head_dim, md.max_seq_len, md.chunk_tokens),
+                      q.device)
+        return ops.decode_attn(q.reshape(B, layer.num_heads * layer.head_dim), k_pool, v_pool,
+                               batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens, self.page_size,
+                               layer.num_heads, md.max_seq_len, chunk_tokens=md.chunk_tokens, workspace=ws)
+
+    def forward_extend(self, q, k, v, layer, batch):
+        md = self.forward_metadata
+        if md is None or md.decode:
+            self.init_forward_metadata(batch)
+            md = self.forward_metadata
+        self._store_kv(k, v, layer, batch)       # first: the new tokens' K/V are read back from the pool
+        k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
+        T = q.shape[0]
+        ws = self._ws(ops.prefill_workspace_bytes(T, layer.num_heads, layer.head_dim, md.max_seq_len), q.device)
+        return ops.prefill_attn(q, k_pool, v_pool, batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
+                                batch.prefix_lens, md.cu_q, self.page_size, layer.num_heads, md.max_extend_len,
+                                md.max_seq_len, workspace=ws)

@@ -1,0 +1,68 @@
+"""KV pools + free-page FIFO with the reference's interface (memory/kvcache.py:5-91).
+
+Differences that do not change results: all layers' K and V pools are carved from ONE HBM allocation
+([layer, K|V, S, Hkv, D]; `k_cache[l]` / `v_cache[l]` are views with the reference's [S, Hkv, D] shape), the
+free list is a deque (O(1) pops instead of list slicing), and `write_kv` is the HIP row scatter instead of
+two `index_put_` launches.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+
+class KVCache:
+    def __init__(self, size: int, page_size: int, head_num: int, head_dim: int, dtype: torch.dtype,
+                 layer_num: int, device: str):
+        self.page_num = size // page_size                                   # kvcache.py:16
+        self.page_size = page_size
+        self.head_num = head_num
+        self.head_dim = head_dim
+        self.dtype = dtype
+        self.layer_num = layer_num
+        self.device = device
+        rows = self.page_num * page_size
+        self._store = torch.zeros((layer_num, 2, rows, head_num, head_dim), dtype=dtype, device=device)
+        self.k_cache = [self._store[l, 0] for l in range(layer_num)]        # kvcache.py:24-35 shapes
+        self.v_cache = [self._store[l, 1] for l in range(layer_num)]
+        self.clear()
+
+    # ---- free-page FIFO: pop from the front, return to the back (kvcache.py:38-67, 87-91)
+    @property
+    def free_pages(self) -> List[int]:
+        return list(self._free)
+
+    def allocate_pages_prefill(self, seq_lens: Sequence[int], prefix_lens: Sequence[int]) -> List[Optional[List[int]]]:
+        ps = self.page_size
+        return [self._allocate_pages(-(-int(s) // ps) - -(-int(p) // ps)) for s, p in zip(seq_lens, prefix_lens)]
+
+    def allocate_pages_decode(self, seq_lens: Sequence[int]) -> List[Optional[List[int]]]:
+        return self.allocate_pages_prefill(seq_lens, [int(s) - 1 for s in seq_lens])
+
+    def _allocate_pages(self, num_pages: int) -> Optional[List[int]]:
+        if num_pages > len(self._free):
+            return None                                                     # kvcache.py:60-61
+        return [self._free.popleft() for _ in range(num_pages)]
+
+    def _free_pages(self, pages: Iterable[int]) -> None:
+        if isinstance(pages, torch.Tensor):
+            pages = pages.tolist()
+        self._free.extend(int(p) for p in pages)
+
+    def clear(self) -> None:
+        self._free = deque(range(self.page_num))
+
+    def available_page_num(self) -> int:
+        return len(self._free)
+
+    # ---- data path
+    def write_kv(self, layer_id: int, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor) -> None:
+        """k_cache[layer][loc] = cache_k; v_cache[layer][loc] = cache_v (kvcache.py:69-79), one HIP launch."""
+        ops.kv_store(self.k_cache[layer_id], self.v_cache[layer_id], loc, cache_k, cache_v)
+
+    def get_kv_cache(self, layer_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.k_cache[layer_id], self.v_cache[layer_id]

@@ -1,0 +1,164 @@
+"""Tensor-level wrappers over the C ABI (one per entry point of include/mi355attn.h).
+
+Every argument tensor must be on the GPU; results are enqueued on torch's current stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, dtype_code, require_cuda
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def kv_store(k_pool: torch.Tensor, v_pool: torch.Tensor, loc: torch.Tensor, k_src: torch.Tensor,
+             v_src: torch.Tensor) -> None:
+    """k_pool[loc] = k_src; v_pool[loc] = v_src  (reference memory/kvcache.py:69-79).
+
+    k_pool/v_pool [S, Hkv, D] contiguous; k_src/v_src [T, Hkv, D] or [T, Hkv*D], rows may be strided
+    (views of the packed qkv projection) but the inner Hkv*D elements must be contiguous."""
+    lib = _lib.load()
+    for n, t in (("k_pool", k_pool), ("v_pool", v_pool), ("loc", loc), ("k_src", k_src), ("v_src", v_src)):
+        require_cuda(t, n)
+    S, Hkv, D = k_pool.shape
+    T = loc.numel()
+    k2, v2 = k_src.view(T, Hkv * D), v_src.view(T, Hkv * D)      # raises if the inner Hkv*D block is not dense
+    if k2.dtype != k_pool.dtype or v2.dtype != v_pool.dtype:
+        # index_put casts the source to the pool dtype (kvcache.py:78-79); do the same, explicitly
+        k2, v2 = k2.to(k_pool.dtype), v2.to(v_pool.dtype)
+    if T and (k2.stride(1) != 1 or v2.stride(1) != 1):
+        raise _lib.MI355AttnError("kv_store: source rows must have inner stride 1")
+    if loc.dtype != torch.int64:
+        raise _lib.MI355AttnError("kv_store: loc must be int64")
+    if not (k_pool.is_contiguous() and v_pool.is_contiguous() and loc.is_contiguous()):
+        raise _lib.MI355AttnError("kv_store: pools and loc must be contiguous")
+    check(lib.m355_kv_store(k_pool.data_ptr(), v_pool.data_ptr(), k2.data_ptr(), v2.data_ptr(),
+                            k2.stride(0) if T else Hkv * D, v2.stride(0) if T else Hkv * D, loc.data_ptr(), T, Hkv, D,
+                            S, dtype_code(k_pool.dtype), current_stream()), "m355_kv_store")
+
+
+def out_cache_loc(page_table: torch.Tensor, row_of_token: torch.Tensor, positions: torch.Tensor,
+                  page_size: int) -> torch.Tensor:
+    """page_table[row, pos // ps] * ps + pos % ps as int64 (reference engine/batch.py:315-317, 341-343)."""
+    lib = _lib.load()
+    for n, t in (("page_table", page_table), ("row_of_token", row_of_token), ("positions", positions)):
+        require_cuda(t, n)
+    assert page_table.dtype == torch.int32 and row_of_token.dtype == torch.int64 and positions.dtype == torch.int64
+    n = positions.numel()
+    out = torch.empty(n, dtype=torch.int64, device=positions.device)
+    check(lib.m355_out_cache_loc(page_table.data_ptr(), page_table.stride(0), row_of_token.contiguous().data_ptr(),
+                                 positions.contiguous().data_ptr(), page_size, n, out.data_ptr(), current_stream()),
+          "m355_out_cache_loc")
+    return out
+
+
+def prefill_prepare(page_table: torch.Tensor, plan: torch.Tensor, pages: torch.Tensor, cu_q: torch.Tensor,
+                    B: int, T: int, page_size: int):
+    """One launch: page-table row writes + positions + row_of_token + out_cache_loc
+    (reference engine/batch.py:280-317).  Returns (positions, row_of_token, out_cache_loc), all int64 [T]."""
+    lib = _lib.load()
+    for n, t in (("page_table", page_table), ("plan", plan), ("pages", pages), ("cu_q", cu_q)):
+        require_cuda(t, n)
+    assert plan.dtype == torch.int32 and pages.dtype == torch.int32 and cu_q.dtype == torch.int32
+    dev = page_table.device
+    positions = torch.empty(T, dtype=torch.int64, device=dev)
+    row_of_token = torch.empty(T, dtype=torch.int64, device=dev)
+    loc = torch.empty(T, dtype=torch.int64, device=dev)
+    check(lib.m355_prefill_prepare(page_table.data_ptr(), page_table.stride(0), plan.data_ptr(), pages.data_ptr(),
+                                   cu_q.data_ptr(), B, page_size, positions.data_ptr(), row_of_token.data_ptr(),
+                                   loc.data_ptr(), current_stream()), "m355_prefill_prepare")
+    return positions, row_of_token, loc
+
+
+def decode_prepare(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: torch.Tensor, new_pages: torch.Tensor,
+                   page_size: int):
+    """One launch: seq_lens + 1 (new tensor, like the reference), page-table scatter of fresh pages, positions,
+    out_cache_loc (reference engine/batch.py:319-343).  Returns (new_seq_lens, positions, out_cache_loc)."""
+    lib = _lib.load()
+    for n, t in (("page_table", page_table), ("rows", rows), ("seq_lens", seq_lens), ("new_pages", new_pages)):
+        require_cuda(t, n)
+    assert rows.dtype == torch.int64 and seq_lens.dtype == torch.int64 and new_pages.dtype == torch.int32
+    assert seq_lens.is_contiguous() and rows.is_contiguous()
+    B = seq_lens.numel()
+    trio = torch.empty((3, B), dtype=torch.int64, device=seq_lens.device)     # new seq_lens | positions | loc
+    check(lib.m355_decode_prepare(page_table.data_ptr(), page_table.stride(0), rows.data_ptr(), seq_lens.data_ptr(),
+                                  trio[0].data_ptr(), new_pages.data_ptr(), B, page_size, trio[1].data_ptr(),
+                                  trio[2].data_ptr(), current_stream()), "m355_decode_prepare")
+    return trio[0], trio[1], trio[2]
+
+
+def decode_workspace_bytes(B: int, Hq: int, D: int, max_seq_len: int, chunk_tokens: int = 0) -> int:
+    return int(_lib.load().m355_decode_workspace_bytes(B, Hq, D, max_seq_len, chunk_tokens))
+
+
+def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, page_table: torch.Tensor,
+                page_table_ids: torch.Tensor, seq_lens: torch.Tensor, page_size: int, num_heads: int,
+                max_seq_len: int, scale: float | None = None, chunk_tokens: int = 0,
+                workspace: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Paged decode attention (reference torch_native_backend.py:121-193).  q [B, Hq*D] (row-strided ok)."""
+    lib = _lib.load()
+    for n, t in (("q", q), ("k_pool", k_pool), ("v_pool", v_pool), ("page_table", page_table),
+                 ("page_table_ids", page_table_ids), ("seq_lens", seq_lens)):
+        require_cuda(t, n)
+    S, Hkv, D = k_pool.shape
+    B = q.shape[0]
+    Hq = num_heads
+    q2 = q.view(B, Hq * D)
+    if q2.stride(1) != 1:
+        q2 = q2.contiguous()
+    if out is None:
+        out = torch.empty((B, Hq * D), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = float(D) ** -0.5          # SDPA default: the reference never passes layer.scale on
+    need = decode_workspace_bytes(B, Hq, D, max_seq_len, chunk_tokens)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    assert page_table.dtype == torch.int32 and page_table_ids.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    check(lib.m355_decode_attn(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), page_table.data_ptr(),
+                               page_table.stride(0), page_table_ids.data_ptr(), seq_lens.data_ptr(), out.data_ptr(),
+                               out.stride(0), B, Hq, Hkv, D, page_size, scale, max_seq_len, chunk_tokens,
+                               _ptr(workspace), ws_bytes, dtype_code(q.dtype), current_stream()), "m355_decode_attn")
+    return out
+
+
+def prefill_workspace_bytes(T: int, Hq: int, D: int, max_seq_len: int) -> int:
+    return int(_lib.load().m355_prefill_workspace_bytes(T, Hq, D, max_seq_len))
+
+
+def prefill_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, page_table: torch.Tensor,
+                 page_table_ids: torch.Tensor, seq_lens: torch.Tensor, prefix_lens: torch.Tensor,
+                 cu_q: torch.Tensor, page_size: int, num_heads: int, max_extend_len: int, max_seq_len: int,
+                 scale: float | None = None, workspace: torch.Tensor | None = None,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+    """Ragged extend attention over cached prefixes (reference torch_native_backend.py:25-119)."""
+    lib = _lib.load()
+    for n, t in (("q", q), ("k_pool", k_pool), ("v_pool", v_pool), ("page_table", page_table),
+                 ("page_table_ids", page_table_ids), ("seq_lens", seq_lens), ("prefix_lens", prefix_lens),
+                 ("cu_q", cu_q)):
+        require_cuda(t, n)
+    S, Hkv, D = k_pool.shape
+    T = q.shape[0]
+    B = seq_lens.numel()
+    Hq = num_heads
+    q2 = q.view(T, Hq * D)
+    if q2.stride(1) != 1:
+        q2 = q2.contiguous()
+    if out is None:
+        out = torch.empty((T, Hq * D), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = float(D) ** -0.5
+    need = prefill_workspace_bytes(T, Hq, D, max_seq_len)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    assert cu_q.dtype == torch.int32 and prefix_lens.dtype == torch.int64
+    check(lib.m355_prefill_attn(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(),
+                                page_table.data_ptr(), page_table.stride(0), page_table_ids.data_ptr(),
+                                seq_lens.data_ptr(), prefix_lens.data_ptr(), cu_q.data_ptr(), out.data_ptr(),
+                                out.stride(0), B, T, max_extend_len, max_seq_len, Hq, Hkv, D, page_size, scale,
+                                _ptr(workspace), ws_bytes, dtype_code(q.dtype), current_stream()), "m355_prefill_attn")
+    return out

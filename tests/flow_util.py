@@ -26,8 +26,12 @@ def fixture_id(path: str) -> str:
     return os.path.basename(path)[len("flow_"):-len(".npz")]
 
 
-def qkv_views(T, Hq, Hkv, D, seed, dtype):
-    qkv = synth((T, (Hq + 2 * Hkv) * D), seed, amp=2.0, dtype=dtype)
+def qkv_packed(T, Hq, Hkv, D, seed, dtype):
+    return synth((T, (Hq + 2 * Hkv) * D), seed, amp=2.0, dtype=dtype)
+
+
+def split_qkv(qkv, Hq, Hkv, D):
+    """q, k, v as strided views of the packed projection output (reference models/llama.py:133-134)."""
     return qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
 
 
@@ -38,7 +42,8 @@ class Phase:
     meta: M.RefBatchMeta           # oracle metadata for this phase
     reqs: list                     # RefReq list (prefill phases) - fill_ids / prefix_ppns as the engine sees them
     next_ids: Optional[list]       # decode phases: the token ids fed in
-    q: torch.Tensor                # [T, Hq*D]   strided view of the packed projection
+    qkv: torch.Tensor              # [T, (Hq+2Hkv)*D] packed projection output
+    q: torch.Tensor                # [T, Hq*D]   strided view of qkv
     k: torch.Tensor                # [T, Hkv*D]
     v: torch.Tensor
     k_pool: torch.Tensor           # oracle pools AFTER this phase's write
@@ -83,10 +88,11 @@ class FlowReplay:
 
         def step(tag, decode, meta, reqs, next_ids, seed):
             T = int(meta.input_ids.shape[0])
-            q, k, v = qkv_views(T, Hq, Hkv, D, seed, dt)
+            qkv = qkv_packed(T, Hq, Hkv, D, seed, dt)
+            q, k, v = split_qkv(qkv, Hq, Hkv, D)
             A.write_kv_ref(k_pool, v_pool, torch.from_numpy(meta.out_cache_loc), k.view(-1, Hkv, D), v.view(-1, Hkv, D))
             out = attend(meta, q, decode)
-            return Phase(tag, decode, meta, reqs, next_ids, q, k, v, k_pool, v_pool, pt.table,
+            return Phase(tag, decode, meta, reqs, next_ids, qkv, q, k, v, k_pool, v_pool, pt.table,
                          list(pool.free_pages), out)
 
         reqs = [M.RefReq(fill_ids=list(self.ids[i][:self.cuts[i]])) for i in range(n)]

@@ -1,0 +1,245 @@
+"""GPU parity: the HIP path (through the C ABI, via mi355_attn) against the oracle and the golden vectors.
+
+Integer / byte results (page tables, positions, out_cache_loc, KV pools) must be bit-exact.  Attention output
+is bf16 and is held to BF16_ATOL/BF16_RTOL of the fp32 reference output stored in the fixtures
+(flow_util.BF16_*: 2e-2 absolute + 2e-2 relative, |v| <= 2 in these inputs)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from flow_util import BF16_ATOL, BF16_RTOL, FlowReplay, fixture_id, flow_fixtures
+from synth import bits16, fnv64, synth
+from oracle import attention_ref as A
+from oracle import memory_ref as M
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+META_FIELDS = ("input_ids", "page_table_ids", "seq_lens", "prefix_lens", "positions", "out_cache_loc")
+
+
+def _mods():
+    import mi355_attn
+    from mi355_attn import ops
+    return mi355_attn, ops
+
+
+@pytest.mark.parametrize("path", flow_fixtures(), ids=fixture_id)
+def test_flow_through_backend(path):
+    """prefill -> extend over cached prefix -> decode steps, driven through Batch + MI355AttnBackend exactly as
+    bench_one_batch drives the reference (bench_one_batch.py:195-259)."""
+    m, ops = _mods()
+    fr = FlowReplay(path, torch.bfloat16)
+    ps, Hq, Hkv, D = fr.ps, fr.Hq, fr.Hkv, fr.D
+    kv = m.KVCache(size=fr.S_pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=1, device=DEV)
+    pm = m.PageManager(page_size=ps, max_req_num=fr.max_req, max_context_len=fr.ctx, device=DEV)
+    backend = m.MI355AttnBackend(SimpleNamespace(device=DEV, page_size=ps, kvcache=kv, page_manager=pm))
+    layer = m.Attention(layer_id=0, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=D ** -0.5)
+    reqs, batch = None, None
+    for ph in fr.phases():
+        if ph.tag == "p1":
+            reqs = [m.Req(i, fr.ids[i][: fr.cuts[i]]) for i in range(fr.n)]
+            for r in reqs:
+                r.fill_ids = list(r.origin_input_ids)
+            batch = m.Batch(reqs, page_manager=pm, kvcache=kv, device=DEV)
+            batch.prepare_for_prefill()
+        elif ph.tag == "p2":
+            for i, r in enumerate(reqs):
+                r.fill_ids = list(fr.ids[i])
+                r.prefix_ppns = pm.page_table[i, : fr.cuts[i] // ps].tolist()
+            batch = m.Batch(reqs, page_manager=pm, kvcache=kv, device=DEV)
+            batch.prepare_for_prefill()
+        else:
+            batch.output_ids = torch.tensor(ph.next_ids, dtype=torch.int64, device=DEV)
+            batch.prepare_for_decode()
+        # ---- metadata: bit-exact against the reference's own values
+        for f in META_FIELDS:
+            got = getattr(batch, f).cpu().numpy()
+            assert got.dtype == np.int64, (ph.tag, f)
+            assert np.array_equal(got, fr.golden(ph.tag, f)), (ph.tag, f, got, fr.golden(ph.tag, f))
+        used = -(-int(ph.meta.seq_lens.max()) // ps)
+        rows = pm.page_table[batch.page_table_ids, :used].cpu().numpy()
+        assert np.array_equal(rows, fr.golden(ph.tag, "page_rows")), ph.tag
+        assert kv.free_pages[:4] == [int(x) for x in fr.golden(ph.tag, "free_head")]
+        # ---- attention (writes K/V first)
+        qkv = ph.qkv.to(DEV)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        backend.init_forward_metadata(batch)
+        batch.attn_backend = backend
+        o = layer(q, k, v, batch)
+        torch.cuda.synchronize()
+        assert o.shape == (q.shape[0], Hq * D) and o.dtype == torch.bfloat16
+        kp, vp = kv.get_kv_cache(0)
+        assert torch.equal(kp.cpu(), ph.k_pool) and torch.equal(vp.cpu(), ph.v_pool), (ph.tag, "KV pools")
+        assert fnv64(bits16(kp)) == int(fr.golden(ph.tag, "k_pool_hash"))
+        assert fnv64(bits16(vp)) == int(fr.golden(ph.tag, "v_pool_hash"))
+        rows_, ref = fr.golden_o_f32(ph.tag)
+        np.testing.assert_allclose(o.float().cpu().numpy()[rows_], ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=ph.tag)
+        np.testing.assert_allclose(o.float().cpu().numpy(), ph.out.float().numpy(), rtol=BF16_RTOL, atol=BF16_ATOL,
+                                   err_msg=ph.tag + " vs oracle bf16")
+
+
+def test_kv_store_edges():
+    m, ops = _mods()
+    S, Hkv, D = 64, 2, 64
+    kp = torch.zeros((S, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    vp = torch.zeros_like(kp)
+    # empty write
+    e = torch.empty((0, Hkv * D), dtype=torch.bfloat16, device=DEV)
+    ops.kv_store(kp, vp, torch.empty(0, dtype=torch.int64, device=DEV), e, e)
+    # strided sources, unordered slots, a negative slot (torch wraps it), last slot
+    T = 5
+    qkv = synth((T, 6 * D), 7, amp=2.0).to(DEV)
+    k, v = qkv[:, 2 * D:4 * D], qkv[:, 4 * D:]
+    loc = torch.tensor([63, 0, 17, -2, 5], dtype=torch.int64, device=DEV)
+    ops.kv_store(kp, vp, loc, k.view(T, Hkv, D), v.view(T, Hkv, D))
+    rk, rv = torch.zeros((S, Hkv, D), dtype=torch.bfloat16), torch.zeros((S, Hkv, D), dtype=torch.bfloat16)
+    A.write_kv_ref(rk, rv, loc.cpu(), k.cpu().view(T, Hkv, D), v.cpu().view(T, Hkv, D))
+    assert torch.equal(kp.cpu(), rk) and torch.equal(vp.cpu(), rv)
+    # fp16 and fp32 pools copy bytes just the same
+    for dt in (torch.float16, torch.float32):
+        kp2 = torch.zeros((S, Hkv, D), dtype=dt, device=DEV)
+        vp2 = torch.zeros_like(kp2)
+        src = synth((T, 2 * Hkv * D), 9, dtype=dt).to(DEV)
+        ops.kv_store(kp2, vp2, loc, src[:, : Hkv * D], src[:, Hkv * D:])
+        rk2, rv2 = torch.zeros((S, Hkv, D), dtype=dt), torch.zeros((S, Hkv, D), dtype=dt)
+        A.write_kv_ref(rk2, rv2, loc.cpu(), src.cpu()[:, : Hkv * D].view(T, Hkv, D), src.cpu()[:, Hkv * D:].view(T, Hkv, D))
+        assert torch.equal(kp2.cpu(), rk2) and torch.equal(vp2.cpu(), rv2)
+    # CPU tensors are refused loudly (no fallback)
+    with pytest.raises(RuntimeError):
+        ops.kv_store(kp.cpu(), vp.cpu(), loc.cpu(), k.cpu(), v.cpu())
+
+
+def test_out_cache_loc_kernel():
+    m, ops = _mods()
+    rng = np.random.default_rng(0)
+    for ps in (1, 3, 16, 256):
+        table = rng.integers(0, 1 << 20, size=(9, 40), dtype=np.int32)
+        rows = rng.integers(0, 9, size=777).astype(np.int64)
+        pos = rng.integers(0, 40 * ps, size=777).astype(np.int64)
+        got = ops.out_cache_loc(torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV),
+                                torch.from_numpy(pos).to(DEV), ps)
+        assert got.dtype == torch.int64
+        assert np.array_equal(got.cpu().numpy(), M.out_cache_loc_ref(table, rows, pos, ps))
+
+
+def _random_paged_case(B, Hq, Hkv, D, ps, lens, seed, shuffle=True):
+    """Pools + page table with physical pages handed out in a shuffled order (non-contiguous gathers)."""
+    g = torch.Generator().manual_seed(seed)
+    npages = sum(-(-l // ps) for l in lens) + 3
+    perm = torch.randperm(npages, generator=g).tolist() if shuffle else list(range(npages))
+    W = max(-(-l // ps) for l in lens) + 2
+    table = np.full((B + 2, W), 0, dtype=np.int32)
+    rows = list(range(B, 0, -1))           # rows deliberately not 0..B-1
+    it = iter(perm)
+    for b, l in enumerate(lens):
+        for j in range(-(-l // ps)):
+            table[rows[b], j] = next(it)
+        table[rows[b], -(-l // ps):] = npages              # stale entries past the live length -> poison page
+    kp = (torch.randn(((npages + 1) * ps, Hkv, D), generator=g) * 1.0).to(torch.bfloat16)
+    vp = (torch.randn(((npages + 1) * ps, Hkv, D), generator=g) * 1.0).to(torch.bfloat16)
+    kp[npages * ps:] = float("nan")                        # in-bounds, but any use of it shows up as NaN
+    vp[npages * ps:] = float("nan")
+    return table, np.asarray(rows, dtype=np.int64), kp, vp
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 64), (32, 8, 128), (8, 1, 128), (16, 4, 128), (4, 4, 64), (4, 2, 128)])
+@pytest.mark.parametrize("ps", [1, 16])
+def test_decode_attn_split_and_merge(Hq, Hkv, D, ps):
+    """Ragged lengths around every chunk boundary, every chunk size; oracle = fp64 formula."""
+    m, ops = _mods()
+    lens = [1, 2, 63, 64, 65, 127, 129, 300, 777, 1025]
+    B = len(lens)
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, lens, seed=Hq + D + ps)
+    g = torch.Generator().manual_seed(1)
+    q = (torch.randn((B, Hq * D), generator=g) * 2).to(torch.bfloat16)
+    ref = A.paged_attn_f64(q.view(B, Hq, D), kp, vp, torch.from_numpy(table), torch.from_numpy(rows),
+                           torch.tensor(lens), None, ps).reshape(B, Hq * D).float().numpy()
+    dq, dk, dv = q.to(DEV), kp.to(DEV), vp.to(DEV)
+    dt, dr, dl = torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV)
+    for chunk in (0, 64, 128, 256, 1024):
+        o = ops.decode_attn(dq, dk, dv, dt, dr, dl, ps, Hq, max(lens), chunk_tokens=chunk)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"chunk={chunk}")
+
+
+def test_decode_attn_softmax_spike():
+    """One key dominates (forces the running-max rescale late in a chunk and across chunks)."""
+    m, ops = _mods()
+    Hq, Hkv, D, ps = 8, 2, 64, 16
+    lens = [500]
+    table, rows, kp, vp = _random_paged_case(1, Hq, Hkv, D, ps, lens, seed=5)
+    q = torch.ones((1, Hq * D), dtype=torch.bfloat16)
+    slot = int(table[rows[0], 431 // ps]) * ps + 431 % ps
+    kp[slot] = 4.0                                      # q.k = 4*64 -> towers over N(0, 8) scores
+    ref = A.paged_attn_f64(q.view(1, Hq, D), kp, vp, torch.from_numpy(table), torch.from_numpy(rows),
+                           torch.tensor(lens), None, ps).reshape(1, -1).float().numpy()
+    for chunk in (64, 1024):
+        o = ops.decode_attn(q.to(DEV), kp.to(DEV), vp.to(DEV), torch.from_numpy(table).to(DEV),
+                            torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV), ps, Hq, 500, chunk_tokens=chunk)
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,ps", [(32, 8, 64, 16), (32, 8, 128, 16), (8, 1, 128, 1), (16, 4, 128, 256)])
+def test_prefill_attn_ragged_prefix(Hq, Hkv, D, ps):
+    """Mixed zero / non-zero / non-page-aligned-length prefixes, extends of 1..300 tokens."""
+    m, ops = _mods()
+    seq = [5, 40, 333, 64, 257, 1200]
+    pre = [0, 32, 48, 63, 256, 1100]
+    pre = [p // ps * ps for p in pre]                   # prefixes are whole pages (batch.py:256)
+    B = len(seq)
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, seq, seed=D + ps)
+    ext = [s - p for s, p in zip(seq, pre)]
+    T = sum(ext)
+    g = torch.Generator().manual_seed(2)
+    q = (torch.randn((T, Hq * D), generator=g) * 2).to(torch.bfloat16)
+    ref = A.paged_attn_f64(q.view(T, Hq, D), kp, vp, torch.from_numpy(table), torch.from_numpy(rows),
+                           torch.tensor(seq), torch.tensor(pre), ps).reshape(T, Hq * D).float().numpy()
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(ext)]), dtype=torch.int32, device=DEV)
+    o = ops.prefill_attn(q.to(DEV), kp.to(DEV), vp.to(DEV), torch.from_numpy(table).to(DEV),
+                         torch.from_numpy(rows).to(DEV), torch.tensor(seq, device=DEV), torch.tensor(pre, device=DEV),
+                         cu, ps, Hq, max(ext), max(seq))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+
+
+def test_decode_cfg2_full_size_properties():
+    """BASELINE.json configs[1] at full size (1B heads, B=64 ragged 146..2046, ps=16, shuffled pages):
+    the result must not depend on the chunking, and must match a torch fp32 computation on the GPU."""
+    import random
+    m, ops = _mods()
+    Hq, Hkv, D, ps = 32, 8, 64, 16
+    random.seed(0)
+    lens = [random.randint(64, 2048) for _ in range(64)]
+    assert sum(lens) == 73961
+    lens = [l + 1 for l in lens]
+    B = len(lens)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    npages = sum(-(-l // ps) for l in lens)
+    perm = torch.randperm(npages, generator=torch.Generator().manual_seed(0))
+    W = 8192 // ps
+    table = torch.zeros((B, W), dtype=torch.int32)
+    off = 0
+    for b, l in enumerate(lens):
+        n = -(-l // ps)
+        table[b, :n] = perm[off:off + n].to(torch.int32)
+        off += n
+    kp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    vp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    q = torch.randn((B, Hq * D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
+    outs = [ops.decode_attn(q, kp, vp, dt, dr, dl, ps, Hq, max(lens), chunk_tokens=c).float() for c in (0, 128, 1024)]
+    for o in outs[1:]:
+        assert torch.allclose(o, outs[0], rtol=BF16_RTOL, atol=BF16_ATOL)
+    # torch fp32 reference on the GPU, one sequence at a time (same gather as the reference backend)
+    ref = torch.empty((B, Hq, D), device=DEV)
+    for b, l in enumerate(lens):
+        pos = torch.arange(l, device=DEV)
+        slots = dt[b, pos // ps].long() * ps + pos % ps
+        k = kp[slots].float().repeat_interleave(Hq // Hkv, dim=1)      # [L, Hq, D]
+        v = vp[slots].float().repeat_interleave(Hq // Hkv, dim=1)
+        s = torch.einsum("hd,lhd->hl", q[b].view(Hq, D).float(), k) * D ** -0.5
+        ref[b] = torch.einsum("hl,lhd->hd", torch.softmax(s, dim=-1), v)
+    assert torch.allclose(outs[0], ref.view(B, -1), rtol=BF16_RTOL, atol=BF16_ATOL)
