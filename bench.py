@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=-1, help="decode chunk tokens override (-1: backend heuristic)")
+    ap.add_argument("--heads", type=str, default="", help="experiment: Hq,Hkv,D per GPU instead of the 1B shape")
+    ap.add_argument("--copies", type=int, default=0, help="experiment: batch = 64 * copies")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,8 +91,10 @@ def main():
     tp = world
     Hq, Hkv, D, L, hidden = MODEL["Hq"] // tp, MODEL["Hkv"] // tp, MODEL["D"], MODEL["layers"], MODEL["hidden"]
     assert Hkv >= 1, "tp > num_kv_heads is not a reference configuration"
+    if args.heads:
+        Hq, Hkv, D = (int(x) for x in args.heads.split(","))
     ps = PAGE_SIZE
-    lens0 = cfg2_lengths(tp)                         # global batch 64 * tp
+    lens0 = cfg2_lengths(args.copies or tp)          # global batch 64 * tp
     B = len(lens0)
     total_steps = args.warmup + args.steps + 8
     pages_needed = sum(-(-(l + total_steps) // ps) for l in lens0) + 8

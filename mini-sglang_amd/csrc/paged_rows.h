@@ -4,7 +4,7 @@
 
 namespace m355 {
 
-constexpr int kRowsMaxChunk = 1024;
+constexpr int kRowsMaxChunk = 512;
 
 int paged_rows_attn(const void* q, int64_t q_stride, const void* k_pool, const void* v_pool, const int32_t* page_table,
                     int64_t pt_stride, const int64_t* row_ids, const int64_t* kv_lens, const int32_t* cu_q,

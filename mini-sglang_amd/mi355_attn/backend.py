@@ -34,10 +34,10 @@ class ForwardMetadata:
 
 def pick_decode_chunk(total_tokens: int, num_kv_heads: int) -> int:
     """Tokens per wave for decode.  One wave streams one (request, kv head, chunk); aim for ~8 waves on each
-    of the 256 CUs, keep chunks >= 128 tokens (partials cost ~G/chunk extra traffic) and <= 1024 (LDS page
+    of the 256 CUs, keep chunks >= 128 tokens (partials cost ~G/chunk extra traffic) and <= 512 (LDS slot
     staging).  Uses the exact token total, which the host knows."""
     want_items = 2048
-    chunk = 1024
+    chunk = 512
     while chunk > 128 and (total_tokens // chunk + 1) * num_kv_heads < want_items:
         chunk //= 2
     if (total_tokens // chunk + 1) * num_kv_heads < 512:

@@ -71,7 +71,11 @@ class FlowReplay:
             assert np.array_equal(np.asarray(self.ids[i]), g[f"ids{i}"]), "synth_ints drifted from the fixture"
         self.max_req = 2 * self.n + 1
 
-    def phases(self) -> Iterator[Phase]:
+    def phases_meta_only(self) -> Iterator[Phase]:
+        """Same walk without tensors: only tag / decode / meta / table / free_pages are filled in."""
+        return self.phases(compute=False)
+
+    def phases(self, compute: bool = True) -> Iterator[Phase]:
         ps, Hq, Hkv, D, n, dt = self.ps, self.Hq, self.Hkv, self.D, self.n, self.dtype
         pool = M.RefPagePool(self.S_pages, ps)
         pt = M.RefPageTable(ps, self.max_req, self.ctx)
@@ -87,6 +91,9 @@ class FlowReplay:
             return A.extend_attn_ref(q.reshape(T, Hq, D), *args, torch.from_numpy(meta.prefix_lens), ps).reshape(T, Hq * D)
 
         def step(tag, decode, meta, reqs, next_ids, seed):
+            if not compute:
+                return Phase(tag, decode, meta, reqs, next_ids, None, None, None, None, None, None, pt.table,
+                             list(pool.free_pages), None)
             T = int(meta.input_ids.shape[0])
             qkv = qkv_packed(T, Hq, Hkv, D, seed, dt)
             q, k, v = split_qkv(qkv, Hq, Hkv, D)

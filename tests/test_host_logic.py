@@ -1,0 +1,189 @@
+"""CPU: the product's HOST logic (no device kernels): page/row allocation plans, the radix tree, the C-ABI
+surface, and loud failure when a device operation is attempted without a GPU."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from flow_util import FlowReplay, fixture_id, flow_fixtures
+from oracle import memory_ref as M
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _m():
+    import mi355_attn
+    return mi355_attn
+
+
+# ------------------------------------------------------------------------------------------------
+# C ABI surface
+# ------------------------------------------------------------------------------------------------
+def _declared_symbols():
+    with open(os.path.join(REPO, "include", "mi355attn.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(m355_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mi355_attn import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    lib = _lib.load()                                   # raises if the .so or a bound symbol is missing
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mi355attn.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(m355_[a-z0-9_]+)\b", out))
+    assert set(declared) <= exported
+    assert lib.m355_version() == 100
+    assert b"workspace" in lib.m355_strerror(-3)
+
+
+def test_device_ops_refuse_cpu_tensors():
+    m = _m()
+    from mi355_attn import ops
+    kv = m.KVCache(size=32, page_size=4, head_num=2, head_dim=64, dtype=torch.bfloat16, layer_num=1, device="cpu")
+    with pytest.raises(RuntimeError, match="GPU"):
+        kv.write_kv(0, torch.zeros(1, dtype=torch.int64), torch.zeros(1, 2, 64, dtype=torch.bfloat16),
+                    torch.zeros(1, 2, 64, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.out_cache_loc(torch.zeros((2, 2), dtype=torch.int32), torch.zeros(1, dtype=torch.int64),
+                          torch.zeros(1, dtype=torch.int64), 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# allocation plans against the reference's page tables
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", flow_fixtures(), ids=fixture_id)
+def test_plans_reproduce_reference_page_tables(path):
+    m = _m()
+    from mi355_attn.batch import plan_decode, plan_prefill
+    fr = FlowReplay(path, torch.bfloat16)
+    ps = fr.ps
+    kv = m.KVCache(size=fr.S_pages * ps, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+    pm = m.PageManager(page_size=ps, max_req_num=fr.max_req, max_context_len=fr.ctx, device="cpu")
+    table = np.zeros((fr.max_req, fr.ctx // ps), dtype=np.int32)     # what the metadata kernel would write
+    reqs, lens, rows = None, None, None
+    for ph in fr.phases_meta_only():
+        if not ph.decode:
+            if ph.tag == "p1":
+                reqs = [m.Req(i, fr.ids[i][: fr.cuts[i]]) for i in range(fr.n)]
+                for r in reqs:
+                    r.fill_ids = list(r.origin_input_ids)
+            else:
+                for i, r in enumerate(reqs):
+                    r.fill_ids = list(fr.ids[i])
+                    r.prefix_ppns = [int(x) for x in table[i, : fr.cuts[i] // ps]]
+            plan = plan_prefill(reqs, pm, kv)
+            rows, lens = plan.rows, plan.seq_lens
+            assert np.array_equal(plan.input_ids, fr.golden(ph.tag, "input_ids"))
+            assert plan.rows == fr.golden(ph.tag, "page_table_ids").tolist()
+            assert plan.seq_lens == fr.golden(ph.tag, "seq_lens").tolist()
+            assert plan.prefix_lens == fr.golden(ph.tag, "prefix_lens").tolist()
+            assert [r.page_table_id for r in reqs] == plan.rows
+            # emulate m355_prefill_prepare on the host to check the plan's content end to end
+            pos, rot = [], []
+            for b, row in enumerate(plan.rows):
+                pg = plan.pages[plan.page_off[b]: plan.page_off[b + 1]]
+                assert len(pg) == -(-plan.seq_lens[b] // ps)
+                table[row, : len(pg)] = pg
+                pos += list(range(plan.prefix_lens[b], plan.seq_lens[b]))
+                rot += [row] * (plan.seq_lens[b] - plan.prefix_lens[b])
+            assert plan.cu_q.tolist() == np.concatenate([[0], np.cumsum(np.array(plan.seq_lens) - np.array(plan.prefix_lens))]).tolist()
+            packed = plan.packed_i32()
+            assert packed.dtype == np.int32 and packed.size == (fr.n + 1) * 5 + len(plan.pages)
+        else:
+            lens, new_pages = plan_decode(lens, kv)
+            pos = [l - 1 for l in lens]
+            rot = rows
+            for b, row in enumerate(rows):
+                if new_pages[b] >= 0:
+                    table[row, pos[b] // ps] = new_pages[b]
+            assert lens == fr.golden(ph.tag, "seq_lens").tolist()
+        assert np.array_equal(np.asarray(pos), fr.golden(ph.tag, "positions"))
+        loc = M.out_cache_loc_ref(table, np.asarray(rot), np.asarray(pos), ps)
+        assert np.array_equal(loc, fr.golden(ph.tag, "out_cache_loc")), ph.tag
+        used = -(-max(lens) // ps)
+        assert np.array_equal(table[np.asarray(rows), :used], fr.golden(ph.tag, "page_rows")), ph.tag
+        assert kv.free_pages[:4] == [int(x) for x in fr.golden(ph.tag, "free_head")]
+
+
+def test_pool_exhaustion_is_an_error_not_a_none():
+    m = _m()
+    from mi355_attn.batch import plan_prefill
+    kv = m.KVCache(size=8, page_size=4, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+    pm = m.PageManager(page_size=4, max_req_num=2, max_context_len=64, device="cpu")
+    r = m.Req(0, list(range(9)))
+    r.fill_ids = r.origin_input_ids
+    with pytest.raises(RuntimeError, match="exhausted"):
+        plan_prefill([r], pm, kv)
+    assert kv._allocate_pages(3) is None and kv.available_page_num() == 2     # kvcache.py:60-61 behaviour kept
+
+
+# ------------------------------------------------------------------------------------------------
+# radix tree against the reference traces
+# ------------------------------------------------------------------------------------------------
+def _traces():
+    with open(os.path.join(REPO, "tests", "golden", "radix_traces.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_traces().keys()))
+def test_radix_cache_trace(name):
+    m = _m()
+    from mi355_attn.batch import plan_prefill
+    tr = _traces()[name]
+    ps, prompts = tr["ps"], tr["prompts"]
+    ctx = (max(len(p) for p in prompts) + 8) // ps * ps + ps
+    kv = m.KVCache(size=tr["n_pages"] * ps, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+    pm = m.PageManager(page_size=ps, max_req_num=len(prompts) + 1, max_context_len=ctx, device="cpu")
+    tree = m.PagedRadixCache(pm, kv)
+    steps = iter(tr["steps"])
+
+    def check(op, **extra):
+        g = next(steps)
+        assert g["op"] == op
+        assert kv.free_pages == g["free_pages"], (op, extra)
+        assert (tree.evictable_size(), tree.protected_size(), tree.total_size()) == (g["evictable"], g["protected"], g["total"]), op
+        for k_, v_ in extra.items():
+            assert g[k_] == v_, (op, k_, g[k_], v_)
+
+    reqs = []
+    for i, p in enumerate(prompts):
+        r = m.Req(i, list(p), m.SamplingParams(max_new_tokens=4))
+        r.init_next_round_input(tree)
+        plan = plan_prefill([r], pm, kv)
+        pg = plan.pages.tolist()
+        pm.write_ppns_prefill(r.page_table_id, pg)                  # what m355_prefill_prepare does on the GPU
+        pos = np.arange(plan.prefix_lens[0], plan.seq_lens[0])
+        loc = M.out_cache_loc_ref(pm.page_table.numpy(), np.full(len(pos), r.page_table_id), pos, ps)
+        used = -(-len(p) // ps)
+        check("prefill", req=i, prefix_ppns=list(r.prefix_ppns), prefix_len=plan.prefix_lens[0], row=r.page_table_id,
+              page_row=pm.page_table[r.page_table_id, :used].tolist(), out_cache_loc=loc.tolist())
+        r.output_ids.append(7000 + i)
+        tree.cache_unfinished_req(r)
+        check("cache_unfinished", req=i, prefix_ppns=list(r.prefix_ppns), page_row=pm.page_table[r.page_table_id, :used].tolist())
+        reqs.append(r)
+    for i in tr["finish_order"]:
+        reqs[i].output_ids.append(7100 + i)
+        tree.cache_finished_req(reqs[i])
+        check("cache_finished", req=i, free_rows=pm.free_slots)
+    for npg in tr["evict_pages"]:
+        tree.evict(npg)
+        check("evict", num_pages=npg)
+    probe = list(prompts[0]) + [1, 2, 3]
+    val, _ = tree.match_prefix(probe)
+    check("match", key=probe, ppns=val)
+
+
+def test_decode_chunk_heuristic_bounds():
+    from mi355_attn.backend import pick_decode_chunk
+    for total, hkv in [(1, 1), (130, 8), (74025, 8), (32768, 1), (32 * 32768, 1), (10 ** 7, 8)]:
+        c = pick_decode_chunk(total, hkv)
+        assert c in (64, 128, 256, 512)
+    assert pick_decode_chunk(74025, 8) == 256            # cfg2: ~2.3k waves of 256 tokens
