@@ -170,10 +170,17 @@ def main():
     pools = [kv.get_kv_cache(l) for l in range(L)]
     out = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=dev)
 
+    planned = backend.decode_mode == "planned"
+    if planned:
+        ws = backend._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), dev)
+
     def attn_only():
         for kp, vp in pools:
-            ops.decode_attn(q, kp, vp, pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, md.max_seq_len,
-                            chunk_tokens=md.chunk_tokens, workspace=ws, out=out)
+            if planned:
+                ops.decode_attn_planned(q, kp, vp, md.plan, Hq, workspace=ws, out=out)
+            else:
+                ops.decode_attn(q, kp, vp, pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, md.max_seq_len,
+                                chunk_tokens=md.chunk_tokens, workspace=ws, out=out)
 
     attn_only()
     torch.cuda.synchronize()
@@ -199,9 +206,11 @@ def main():
             "config": {"workload": "Llama-3.2-1B decode attention path (kv_store + paged decode attn, 16 layers), "
                                    f"batch {B} ragged 64..2048 (+ctx), page_size 16, shuffled pages",
                        "global_batch": B, "sum_seq_len": sum(lens_now), "page_size": ps, "layers": L,
-                       "heads_per_gpu": [Hq, Hkv, D], "parallelism": f"tp{tp}", "decode_chunk_tokens": md.chunk_tokens},
+                       "heads_per_gpu": [Hq, Hkv, D], "parallelism": f"tp{tp}", "decode_mode": backend.decode_mode,
+                       "decode_chunk_tokens": md.chunk_tokens},
             "pct_of_hbm_peak_whole_step": round(100 * value / tp / HBM_PEAK_GBPS, 2),
-            "roofline": {"kernel": "m355::decode_split_kernel (+ decode_merge_kernel)", "bound": "hbm",
+            "roofline": {"kernel": "m355::decode_stream_kernel (+ stream_merge_kernel)" if planned
+                         else "m355::decode_split_kernel (+ decode_merge_kernel)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "us_per_launch": round(us_per_launch, 3), "algorithmic_bytes_per_launch": bytes_launch},

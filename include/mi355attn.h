@@ -103,6 +103,26 @@ int m355_decode_attn(const void *q, int64_t q_row_stride, const void *k_pool, co
                      int32_t chunk_tokens, void *workspace, int64_t workspace_bytes, int32_t dtype,
                      void *stream);
 
+/* Planned decode attention: the same result as m355_decode_attn, with the batch's token stream laid out
+ * once per forward (the page tables are shared by all layers) and then cut into equal ranges, one per wave, so
+ * that the chip is filled exactly once with no per-chunk start-up.  This is the counterpart of the reference's
+ * per-forward metadata step (FlashAttentionBackend.init_forward_metadata, flash_attention_backend.py:53-84).
+ *   m355_decode_plan          once per forward, after the page table is final: builds `plan` (device memory of
+ *                             m355_decode_plan_bytes bytes, 16-byte aligned) from seq_lens / page_table_ids /
+ *                             page_table.  token_capacity must be >= sum(seq_lens) (a smaller value truncates).
+ *   m355_decode_attn_planned  once per layer, after m355_kv_store; same B, Hq, Hkv, D, token_capacity as the plan.
+ *                             workspace: m355_decode_planned_workspace_bytes bytes, fp32 partials. */
+int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity);
+int m355_decode_plan(const int64_t *seq_lens, const int64_t *page_table_ids, const int32_t *page_table,
+                     int64_t pt_row_stride, int32_t B, int32_t page_size, int32_t Hkv, int32_t D, int32_t G,
+                     int64_t token_capacity, void *plan, int64_t plan_bytes, void *stream);
+int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                                            int64_t token_capacity);
+int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
+                             const void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                             int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
+                             int64_t workspace_bytes, int32_t dtype, void *stream);
+
 /* Ragged prefill ("extend") attention over cached prefixes.  Replaces
  * TorchNativeAttnBackend.forward_extend / _run_sdpa_forward_extend
  * (torch_native_backend.py:25-119, 195-235) minus the KV write: packed query row cu_q[b] + j is

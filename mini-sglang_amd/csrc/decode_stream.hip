@@ -1,0 +1,615 @@
+// Planned ("stream-split") paged decode attention for gfx950.
+//
+// m355_decode_attn (decode_attn.hip) gives every (request, kv head, chunk) its own wave.  Measured on MI355X its
+// loop phase streams K/V at ~6 TB/s, but each wave pays ~4.5 us of dependent loads before its first tile and
+// ~3 us after its last, ragged batches leave dead blocks and a tail, and with one round of waves nothing hides
+// any of it.  Here the work is laid out once per forward instead (the page tables are the same for all layers):
+//
+//   plan  (m355_decode_plan, 2 small launches per forward)
+//     cum[b]       exclusive prefix sum of seq_lens: the batch's tokens form one flat stream of `total` tokens
+//     R            tokens per range = ceil(total / waves-per-head); range r = flat tokens [r*R, (r+1)*R)
+//     rec[r]       range record: length, and its PIECES (request, start inside the range, length, partial index) -
+//                  a range crosses request boundaries
+//     slots[r][i]  KV-pool slot of the i-th token of range r (page-table lookup done once, not once per layer)
+//   attention (m355_decode_attn_planned, per layer): grid = Hkv x NWH single-wave workgroups, exactly filling the
+//     chip; wave (h, w) walks ranges w, w+NWH, ...  Record and slots sit at addresses that depend on r only, so
+//     they are fetched together by the wave's first loads; the K/V tile pipeline then runs across piece boundaries
+//     without draining; q rows of all pieces are staged in LDS; a piece that covers its whole request writes bf16
+//     output directly, the others write fp32 (m, l, acc) partials for the merge kernel.
+//
+// Every wave gets the same number of tokens, so there is one round, no tail and no dead blocks.
+// Algorithmic bytes are those of decode_attn.hip; the plan adds 4 bytes per token per forward.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace m355 {
+
+constexpr int kRMax = 1024;                     // tokens per range (LDS slot staging: 4 KiB)
+constexpr int kMaxPieces = 8;                   // pieces a range record holds (more: the range is walked by scanning cum)
+constexpr int kRec = 4 + 4 * kMaxPieces + 4;    // ints per record: n, np|-1, b0, g0, pieces{b,start,len,pidx}, pad
+constexpr int kSpec = 5;                        // slots loaded per lane together with the record (5*64 = 320 tokens)
+constexpr int kHdrInts = 8;
+
+// Dev-only timing probe (tools/stamp_decode.py): s_memrealtime per wave at phase boundaries when enabled.
+__device__ unsigned long long* g_sstamp_buf = nullptr;
+template <bool ON>
+__device__ __forceinline__ void sstamp(int k) {
+    if constexpr (ON)
+        if (g_sstamp_buf && threadIdx.x == 0) g_sstamp_buf[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
+
+// plan buffer (int32 words): hdr[8] | cum[B+1] | pbase[B+1] | rec[max_ranges][kRec] | slots[max_ranges][kRMax]
+struct PlanLayout {
+    int64_t cum, pbase, rec, slots, ints;
+    int32_t max_ranges;
+};
+__host__ __device__ inline PlanLayout plan_layout(int32_t B, int32_t nwh, int64_t cap) {
+    PlanLayout L;
+    L.max_ranges = (int32_t)(nwh + cap / kRMax + 2);
+    L.cum = kHdrInts;
+    L.pbase = L.cum + (B + 1);
+    L.rec = (L.pbase + (B + 1) + 3) & ~(int64_t)3;
+    L.slots = L.rec + (int64_t)L.max_ranges * kRec;
+    L.ints = L.slots + (int64_t)L.max_ranges * kRMax;
+    return L;
+}
+
+struct StreamParams {
+    const uint16_t* q;
+    const uint16_t* k_pool;
+    const uint16_t* v_pool;
+    const int32_t* plan;
+    uint16_t* out;
+    float* ws_o;    // [n_partials, Hq, D]
+    float* ws_ml;   // [n_partials, Hq, 2]
+    int64_t q_stride, o_stride, row_elems;
+    int64_t off_cum, off_pbase, off_rec, off_slots;
+    int32_t B, Hq, Hkv, nwh, max_ranges;
+    float scale_log2;
+};
+
+// ------------------------------------------------------------------------------------------------
+// plan kernels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int upper_bound_minus1(const int32_t* cum, int n, int32_t x) {
+    // largest b in [0, n) with cum[b] <= x    (cum[0] == 0, non-decreasing)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (cum[mid] <= x) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int32_t pieces_of(int32_t a, int32_t e, int32_t R) { return e > a ? (e - 1) / R - a / R + 1 : 0; }
+
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nwh,
+                                                         int32_t r_min, int64_t cap, int32_t* __restrict__ plan,
+                                                         PlanLayout L) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    int32_t* cum = plan + L.cum;
+    int32_t* pbase = plan + L.pbase;
+    const int per = (B + 1023) / 1024;
+    const int lo = tid * per, hi = min(B, lo + per);
+    auto block_scan = [&](int32_t mine) -> int32_t {       // exclusive scan of one value per thread
+        part[tid] = mine;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int32_t v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const int32_t excl = part[tid] - mine;
+        __syncthreads();
+        return excl;
+    };
+    int32_t s = 0;
+    for (int b = lo; b < hi; ++b) s += (int32_t)seq_lens[b];
+    int32_t run = block_scan(s);
+    // lengths are clamped so the stream never exceeds the slot slabs (a too-small capacity truncates, never overruns)
+    const int32_t icap = (int32_t)cap;
+    for (int b = lo; b < hi; ++b) { cum[b] = run < icap ? run : icap; run += (int32_t)seq_lens[b]; }
+    if (tid == 1023) cum[B] = run < icap ? run : icap;     // the last thread's running sum is the grand total
+    __syncthreads();
+    const int32_t total = cum[B];
+    int32_t R = (total + nwh - 1) / nwh;
+    R = R < r_min ? r_min : (R > kRMax ? kRMax : R);
+    const int32_t n_ranges = (total + R - 1) / R;
+    if (tid == 0) { plan[0] = total; plan[1] = R; plan[2] = B; plan[3] = nwh; plan[4] = n_ranges; plan[5] = plan[6] = plan[7] = 0; }
+    // partials per request -> pbase
+    s = 0;
+    for (int b = lo; b < hi; ++b) s += pieces_of(cum[b], cum[b + 1], R);
+    run = block_scan(s);
+    for (int b = lo; b < hi; ++b) { pbase[b] = run; run += pieces_of(cum[b], cum[b + 1], R); }
+    if (tid == 1023) pbase[B] = run;
+    __syncthreads();
+    // range records
+    for (int r = tid; r < L.max_ranges; r += 1024) {
+        int32_t* rec = plan + L.rec + (int64_t)r * kRec;
+        if (r >= n_ranges) { rec[0] = 0; rec[1] = 0; rec[2] = 0; rec[3] = 0; continue; }
+        const int32_t g0 = r * R, g1 = min(total, g0 + R);
+        int b = upper_bound_minus1(cum, B, g0);
+        rec[0] = g1 - g0; rec[2] = b; rec[3] = g0;
+        int np = 0;
+        for (; b < B && cum[b] < g1; ++b) {
+            const int32_t cs = cum[b], ce = cum[b + 1];
+            const int32_t lo2 = max(cs, g0), hi2 = min(ce, g1);
+            if (hi2 <= lo2) continue;                        // empty request
+            if (np == kMaxPieces) { np = -1; break; }        // too many: the attention kernel scans cum itself
+            rec[4 + np * 4 + 0] = b;
+            rec[4 + np * 4 + 1] = lo2 - g0;
+            rec[4 + np * 4 + 2] = hi2 - lo2;
+            rec[4 + np * 4 + 3] = (lo2 == cs && hi2 == ce) ? -1 : pbase[b] + (r - cs / R);
+            ++np;
+        }
+        rec[1] = np;
+    }
+}
+
+__global__ __launch_bounds__(256) void plan_slots_kernel(const int32_t* __restrict__ page_table, int64_t pt_stride,
+                                                         const int64_t* __restrict__ rows, int32_t B, int32_t ps,
+                                                         int32_t* __restrict__ plan, PlanLayout L) {
+    const int32_t total = plan[0], R = plan[1];
+    const int32_t* cum = plan + L.cum;
+    int32_t* slabs = plan + L.slots;
+    for (int32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        const int b = upper_bound_minus1(cum, B, g);
+        const int32_t t = g - cum[b];
+        const int32_t pg = t / ps;
+        const int32_t r = g / R;
+        slabs[(int64_t)r * kRMax + (g - r * R)] = page_table[rows[b] * pt_stride + pg] * ps + (t - pg * ps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention
+// ------------------------------------------------------------------------------------------------
+template <int D, int G>
+struct PieceState {
+    uint32_t q[G][4];
+    float m[G], l[G];
+    float o[G][8];
+};
+
+template <int D, int G, int U>
+__device__ __forceinline__ void stream_compute_tile(PieceState<D, G>& st, const u32x4 (&kt)[U], const u32x4 (&vt)[U],
+                                                    const float (&bias)[U], float scale_log2) {
+    constexpr int LPH = D / 8;
+    float s[U][G];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a = dot2_bf16(st.q[g][w], kt[u][w], a);
+            s[u][g] = a;
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[u][g] = fmaf(group_sum<LPH>(s[u][g]), scale_log2, bias[u]);
+    float alpha[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float mx = st.m[g];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mx = fmaxf(mx, s[u][g]);
+        alpha[g] = exp2_fast(st.m[g] - mx);
+        st.m[g] = mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s[u][g] = exp2_fast(s[u][g] - mx); sum += s[u][g]; }
+        st.l[g] = fmaf(st.l[g], alpha[g], sum);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st.o[g][j] *= alpha[g];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float vf[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { vf[2 * w] = bf16_lo(vt[u][w]); vf[2 * w + 1] = bf16_hi(vt[u][w]); }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st.o[g][j] = fmaf(s[u][g], vf[j], st.o[g][j]);
+    }
+}
+
+// (own, partner) of a value across lanes l and l ^ MASK, MASK in {8, 16, 32}, in VALU only (no LDS round trip):
+// DPP row rotate for 8, v_permlane16_swap / v_permlane32_swap for 16 / 32.  For the swaps which of a / b is "own"
+// depends on the lane, so callers must use them symmetrically - and the same way for every value of one state.
+template <int MASK>
+__device__ __forceinline__ void lane_pair(float x, float& a, float& b) {
+    const unsigned ux = __builtin_bit_cast(unsigned, x);
+    if constexpr (MASK == 8) {
+        a = x;
+        b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, (int)ux, 0x128 /*row_ror:8*/, 0xF, 0xF, true));
+    } else if constexpr (MASK == 16) {
+        // inline asm: with both inputs equal, hipcc (ROCm 7.2) folds the builtin's two results into one register
+        unsigned ua = ux, ub = ux;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ua), "+v"(ub));
+        a = __builtin_bit_cast(float, ua); b = __builtin_bit_cast(float, ub);
+    } else {
+        static_assert(MASK == 32, "lane_pair: unsupported distance");
+        unsigned ua = ux, ub = ux;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ua), "+v"(ub));
+        a = __builtin_bit_cast(float, ua); b = __builtin_bit_cast(float, ub);
+    }
+}
+
+template <int D, int G, int MASK>
+__device__ __forceinline__ void merge_groups_step(PieceState<D, G>& st) {
+    constexpr int LPH = D / 8;
+    if constexpr (MASK >= LPH) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float ma, mb, la, lb;
+            lane_pair<MASK>(st.m[g], ma, mb);
+            lane_pair<MASK>(st.l[g], la, lb);
+            const float mx = fmaxf(ma, mb);
+            const float wa = exp2_fast(ma - mx), wb = exp2_fast(mb - mx);
+            st.l[g] = la * wa + lb * wb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float oa, ob;
+                lane_pair<MASK>(st.o[g][j], oa, ob);
+                st.o[g][j] = oa * wa + ob * wb;
+            }
+            st.m[g] = mx;
+        }
+    }
+}
+
+template <int D, int G, int U, int NB, int W, bool STAMP = false>
+__global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams p) {
+    constexpr int LPH = D / 8;
+    constexpr int NT = kWave / LPH;
+    constexpr int TPI = NT * U;
+    constexpr int QCH = G * D / 8;                       // 16-byte chunks of one piece's q rows
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kRMax + 64 + kMaxPieces * QCH * 4];
+    int32_t* slots = reinterpret_cast<int32_t*>(lds);
+    int32_t* rec = slots + kRMax;                        // record copy; rec[4 + 4k ..] = piece k {b, start, len, pidx}
+    int32_t* pc = rec + 4;
+    u32x4* qs = reinterpret_cast<u32x4*>(lds + kRMax + 64);
+
+    sstamp<STAMP>(0);
+    const int lane = threadIdx.x;
+    const int dchunk = lane % LPH;
+    const int tsub = lane / LPH;
+    const int h = blockIdx.x % p.Hkv;
+    const int w = blockIdx.x / p.Hkv;
+    const int32_t* plan = p.plan;
+    const int64_t lane_off = (int64_t)h * D + dchunk * 8;
+
+    PieceState<D, G> st;
+
+    // One pass = the pieces currently in pc[0 .. np): stage q, then run the K/V tile pipeline across them.
+    auto run_pass = [&](const int np) {
+        int lk = 0, lit = 0;                              // load iterator: piece, tile
+        int ck = 0, cit = 0;                              // compute iterator
+        int l_start = __builtin_amdgcn_readfirstlane(pc[1]);
+        int l_len = __builtin_amdgcn_readfirstlane(pc[2]);
+        int c_len = l_len;
+
+        auto load_tile = [&](u32x4 (&kt)[U], u32x4 (&vt)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int tt = lit * TPI + u * NT + tsub;
+                tt = tt < l_len ? tt : l_len - 1;         // clamp: the row is masked through the score bias
+                const int64_t off = (int64_t)slots[l_start + tt] * p.row_elems + lane_off;
+                kt[u] = *reinterpret_cast<const u32x4*>(p.k_pool + off);
+                vt[u] = *reinterpret_cast<const u32x4*>(p.v_pool + off);
+            }
+            ++lit;
+            if (lit * TPI >= l_len) {                     // next piece
+                ++lk; lit = 0;
+                if (lk < np) {
+                    l_start = __builtin_amdgcn_readfirstlane(pc[lk * 4 + 1]);
+                    l_len = __builtin_amdgcn_readfirstlane(pc[lk * 4 + 2]);
+                }
+            }
+        };
+        auto begin_piece = [&]() {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const u32x4 t = qs[ck * QCH + g * LPH + dchunk];
+                st.q[g][0] = t[0]; st.q[g][1] = t[1]; st.q[g][2] = t[2]; st.q[g][3] = t[3];
+                st.m[g] = kNegBig; st.l[g] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st.o[g][j] = 0.f;
+            }
+        };
+        auto end_piece = [&]() {
+            merge_groups_step<D, G, 8>(st);               // lane groups sit at lane bits >= log2(LPH)
+            merge_groups_step<D, G, 16>(st);
+            merge_groups_step<D, G, 32>(st);
+            if (lane < LPH) {
+                const int b = pc[ck * 4 + 0];
+                const int pidx = pc[ck * 4 + 3];
+                if (pidx < 0) {
+                    uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)h * G * D + dchunk * 8;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float inv = 1.f / st.l[g];
+                        u32x4 wv;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) wv[x] = pack_bf16(st.o[g][2 * x] * inv, st.o[g][2 * x + 1] * inv);
+                        *reinterpret_cast<u32x4*>(op + g * D) = wv;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int64_t idx = (int64_t)pidx * p.Hq + h * G + g;
+                        float* wo = p.ws_o + idx * D + dchunk * 8;
+                        *reinterpret_cast<f32x4*>(wo) = f32x4{st.o[g][0], st.o[g][1], st.o[g][2], st.o[g][3]};
+                        *reinterpret_cast<f32x4*>(wo + 4) = f32x4{st.o[g][4], st.o[g][5], st.o[g][6], st.o[g][7]};
+                        if (dchunk == 0) { p.ws_ml[idx * 2] = st.m[g]; p.ws_ml[idx * 2 + 1] = st.l[g]; }
+                    }
+                }
+            }
+        };
+
+        // first K/V tiles go out before the q rows: both are one dependent level behind the record
+        sstamp<STAMP>(2);
+        u32x4 kb[NB][U], vb[NB][U];
+#pragma unroll
+        for (int j = 0; j < NB - 1; ++j)
+            if (lk < np) load_tile(kb[j], vb[j]);
+        for (int i = lane; i < np * QCH; i += kWave) {
+            const int k = i / QCH, c = i - k * QCH;
+            qs[i] = *reinterpret_cast<const u32x4*>(p.q + (int64_t)pc[k * 4] * p.q_stride + (int64_t)h * G * D + c * 8);
+        }
+        __syncthreads();
+        sstamp<STAMP>(3);
+        while (ck < np) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {               // j static: the NB register tiles rotate by name
+                if (ck < np) {
+                    if (lk < np) load_tile(kb[(j + NB - 1) % NB], vb[(j + NB - 1) % NB]);
+                    if (cit == 0) begin_piece();
+                    float bias[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) bias[u] = (cit * TPI + u * NT + tsub) < c_len ? 0.f : kNegBig;
+                    stream_compute_tile<D, G, U>(st, kb[j], vb[j], bias, p.scale_log2);
+                    ++cit;
+                    if (cit * TPI >= c_len) {
+                        end_piece();
+                        ++ck; cit = 0;
+                        if (ck < np) c_len = __builtin_amdgcn_readfirstlane(pc[ck * 4 + 2]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                 // rec / qs / slots are rewritten next
+    };
+
+    for (int r = w; r < p.max_ranges; r += p.nwh) {
+        // ---- first loads of the wave: the record and (speculatively) the first kSpec*64 slots, in parallel
+        const int32_t* grec = plan + p.off_rec + (int64_t)r * kRec;
+        const int32_t* gslots = plan + p.off_slots + (int64_t)r * kRMax;
+        int32_t rv = 0, sv[kSpec];
+        if (lane < kRec) rv = grec[lane];
+#pragma unroll
+        for (int k = 0; k < kSpec; ++k) sv[k] = gslots[lane + kWave * k];
+        if (lane < kRec) rec[lane] = rv;
+#pragma unroll
+        for (int k = 0; k < kSpec; ++k) slots[lane + kWave * k] = sv[k];
+        __syncthreads();
+        const int32_t n = __builtin_amdgcn_readfirstlane(rec[0]);
+        const int32_t np_rec = __builtin_amdgcn_readfirstlane(rec[1]);
+        if (n == 0) break;                               // past the last range
+        if (n > kSpec * kWave) {
+            for (int i = kSpec * kWave + lane; i < n; i += kWave) slots[i] = gslots[i];
+            __syncthreads();
+        }
+        sstamp<STAMP>(1);
+        if (np_rec >= 0) {
+            run_pass(np_rec);
+        } else {
+            // ---- more than kMaxPieces requests in this range (many tiny requests): scan cum in passes
+            const int32_t* cum = plan + p.off_cum;
+            const int32_t* pbase = plan + p.off_pbase;
+            const int32_t g0 = __builtin_amdgcn_readfirstlane(rec[3]);
+            const int32_t R = plan[1];
+            int b_next = __builtin_amdgcn_readfirstlane(rec[2]);
+            int32_t done = 0;
+            __syncthreads();
+            while (done < n) {
+                const int b = b_next + lane;
+                int32_t cs = 0, ce = 0;
+                if (lane < kMaxPieces && b < p.B) { cs = cum[b]; ce = cum[b + 1]; }
+                const int32_t lo = max(cs, g0 + done), hi = min(ce, g0 + n);
+                const bool have = lane < kMaxPieces && b < p.B && hi > lo;
+                const unsigned long long mask = __ballot(have);
+                const int np = __popcll(mask);
+                if (have) {
+                    const int k = __popcll(mask & ((1ull << lane) - 1));
+                    pc[k * 4 + 0] = b;
+                    pc[k * 4 + 1] = lo - g0;
+                    pc[k * 4 + 2] = hi - lo;
+                    pc[k * 4 + 3] = (lo == cs && hi == ce) ? -1 : pbase[b] + (r - cs / R);
+                }
+                const int last = 63 - __clzll(mask | 1ull);
+                done = __builtin_amdgcn_readfirstlane((np > 0 ? __shfl(hi, last) : g0 + n) - g0);
+                b_next = __builtin_amdgcn_readfirstlane(np > 0 ? b_next + last + 1 : b_next + kMaxPieces);
+                __syncthreads();
+                if (np > 0) run_pass(np);
+            }
+        }
+    }
+    if constexpr (STAMP) { sstamp<STAMP>(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sstamp<STAMP>(5); }
+}
+
+// One wave per (request, q head): combine the partials of requests cut by range boundaries.
+template <int D>
+__global__ __launch_bounds__(64) void stream_merge_kernel(const StreamParams p) {
+    const int b = blockIdx.x / p.Hq;
+    const int hq = blockIdx.x % p.Hq;
+    const int32_t* pbase = p.plan + p.off_pbase;
+    const int32_t* cum = p.plan + p.off_cum;
+    const int32_t R = p.plan[1];
+    const int32_t cs = cum[b], ce = cum[b + 1];
+    const int np = pieces_of(cs, ce, R);
+    if (np <= 1) return;                                  // whole request handled by one wave: output already final
+    const int32_t p0 = pbase[b];
+    constexpr int E = D / kWave;
+    const int lane = threadIdx.x;
+    float mx = kNegBig;
+    for (int s = lane; s < np; s += kWave) mx = fmaxf(mx, p.ws_ml[((int64_t)(p0 + s) * p.Hq + hq) * 2]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float den = 0.f, acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    for (int s = 0; s < np; ++s) {
+        const int64_t idx = (int64_t)(p0 + s) * p.Hq + hq;
+        const float wgt = exp2_fast(p.ws_ml[idx * 2] - mx);
+        den += wgt * p.ws_ml[idx * 2 + 1];
+        const float* wo = p.ws_o + idx * D + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += wgt * wo[e];
+    }
+    const float inv = 1.f / den;
+    uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)hq * D + lane * E;
+    if constexpr (E == 2) {
+        *reinterpret_cast<uint32_t*>(op) = pack_bf16(acc[0] * inv, acc[1] * inv);
+    } else {
+        const __bf16 bb = (__bf16)(acc[0] * inv);
+        *op = __builtin_bit_cast(uint16_t, bb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int num_cus() {
+    static int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+// Launch shape per group size: {U, NB, waves per SIMD}.  M355_STREAM_VARIANT is a tuning hook (0 = default).
+static int stream_variant() {
+    static int v = [] { const char* e = getenv("M355_STREAM_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+struct StreamShape { int U, NB, W; };
+static inline StreamShape stream_shape(int G) {
+    const int v = stream_variant();
+    if (G >= 8) return v == 1 ? StreamShape{1, 4, 2} : StreamShape{2, 2, 2};
+    if (G == 4) {
+        switch (v) {
+            case 1: return {2, 2, 3};
+            case 2: return {2, 4, 2};
+            case 3: return {2, 3, 3};
+            default: return {2, 3, 2};
+        }
+    }
+    return v == 1 ? StreamShape{2, 4, 3} : StreamShape{2, 3, 3};
+}
+static inline int stream_nwh(int Hkv, int G) {
+    const int n = num_cus() * 4 * stream_shape(G).W / Hkv;
+    return n < 1 ? 1 : n;
+}
+static inline int stream_rmin(int D, int G) { return 4 * (kWave / (D / 8)) * stream_shape(G).U; }   // >= 4 tiles per range
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev-only (not part of include/mi355attn.h)
+    return hipMemcpyToSymbol(HIP_SYMBOL(m355::g_sstamp_buf), &dev_ptr, sizeof(dev_ptr)) == hipSuccess ? 0 : -1;
+}
+
+extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
+    if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
+    (void)D;
+    return plan_layout(B, stream_nwh(Hkv, G), token_capacity).ints * (int64_t)sizeof(int32_t);
+}
+
+extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_table_ids, const int32_t* page_table,
+                                int64_t pt_row_stride, int32_t B, int32_t page_size, int32_t Hkv, int32_t D, int32_t G,
+                                int64_t token_capacity, void* plan, int64_t plan_bytes, void* stream) {
+    if (B == 0) return M355_OK;
+    if (!seq_lens || !page_table_ids || !page_table || !plan || B < 0 || page_size <= 0 || Hkv <= 0 || token_capacity <= 0)
+        return M355_ERR_INVALID_ARG;
+    if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
+    if (token_capacity > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
+    const int nwh = stream_nwh(Hkv, G);
+    const PlanLayout L = plan_layout(B, nwh, token_capacity);
+    if (plan_bytes < L.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, nwh, stream_rmin(D, G), token_capacity,
+                       (int32_t*)plan, L);
+    int64_t blocks = (token_capacity + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(plan_slots_kernel, dim3((unsigned)blocks), dim3(256), 0, st, page_table, pt_row_stride,
+                       page_table_ids, B, page_size, (int32_t*)plan, L);
+    return check_launch();
+}
+
+extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                                                       int64_t token_capacity) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return 0;
+    const PlanLayout L = plan_layout(B, stream_nwh(Hkv, Hq / Hkv), token_capacity);
+    const int64_t n_partials = (int64_t)L.max_ranges + B;      // every range boundary and request adds at most one
+    return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
+}
+
+template <int D, int G>
+static void launch_stream(const StreamParams& p, hipStream_t st) {
+    const dim3 grid((unsigned)(p.Hkv * p.nwh)), block(64);
+    const StreamShape sh = stream_shape(G);
+    const bool stamp = getenv("M355_STREAM_STAMP") != nullptr;
+#define M355_SHAPE(UU, NN, WW) if (sh.U == UU && sh.NB == NN && sh.W == WW) { \
+        if (stamp) hipLaunchKernelGGL((decode_stream_kernel<D, G, UU, NN, WW, true>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((decode_stream_kernel<D, G, UU, NN, WW>), grid, block, 0, st, p); }
+    if constexpr (G >= 8) { M355_SHAPE(1, 4, 2) M355_SHAPE(2, 2, 2) }
+    else if constexpr (G == 4) { M355_SHAPE(2, 2, 3) M355_SHAPE(2, 4, 2) M355_SHAPE(2, 3, 3) M355_SHAPE(2, 3, 2) }
+    else { M355_SHAPE(2, 4, 3) M355_SHAPE(2, 3, 3) }
+#undef M355_SHAPE
+    hipLaunchKernelGGL((stream_merge_kernel<D>), dim3((unsigned)(p.B * p.Hq)), block, 0, st, p);
+}
+
+extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
+                                        const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                        int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
+                                        int64_t workspace_bytes, int32_t dtype, void* stream) {
+    if (B == 0) return M355_OK;
+    if (!q || !k_pool || !v_pool || !plan || !out || B < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || token_capacity <= 0)
+        return M355_ERR_INVALID_ARG;
+    if (dtype != M355_DTYPE_BF16) return M355_ERR_UNSUPPORTED;
+    if (D != 64 && D != 128) return M355_ERR_UNSUPPORTED;
+    const int G = Hq / Hkv;
+    if (G != 1 && G != 2 && G != 4 && G != 8) return M355_ERR_UNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)k_pool | (uintptr_t)v_pool | (uintptr_t)out | (uintptr_t)plan) & 15)
+        return M355_ERR_INVALID_ARG;
+    if ((q_row_stride % 8) || (o_row_stride % 8) || q_row_stride < (int64_t)Hq * D || o_row_stride < (int64_t)Hq * D)
+        return M355_ERR_INVALID_ARG;
+    const int nwh = stream_nwh(Hkv, G);
+    const PlanLayout L = plan_layout(B, nwh, token_capacity);
+    const int64_t n_partials = (int64_t)L.max_ranges + B;
+    const int64_t need = n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return M355_ERR_WORKSPACE;
+    StreamParams p;
+    p.q = (const uint16_t*)q; p.k_pool = (const uint16_t*)k_pool; p.v_pool = (const uint16_t*)v_pool;
+    p.plan = (const int32_t*)plan; p.out = (uint16_t*)out;
+    p.ws_o = (float*)workspace; p.ws_ml = p.ws_o + n_partials * Hq * D;
+    p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = (int64_t)Hkv * D;
+    p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_rec = L.rec; p.off_slots = L.slots;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.nwh = nwh; p.max_ranges = L.max_ranges; p.scale_log2 = scale * kLog2e;
+    hipStream_t st = (hipStream_t)stream;
+#define M355_CASE(DD, GG) if (D == DD && G == GG) { launch_stream<DD, GG>(p, st); return check_launch(); }
+    M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
+    M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)
+#undef M355_CASE
+    return M355_ERR_UNSUPPORTED;
+}

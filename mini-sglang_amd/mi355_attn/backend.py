@@ -13,6 +13,7 @@ with the reference's own Batch (then lengths are read back once per forward, as 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -28,6 +29,7 @@ class ForwardMetadata:
     max_seq_len: int
     max_extend_len: int = 1
     chunk_tokens: int = 0
+    plan: Optional[object] = None                  # ops.DecodePlan, decode only
     cu_q: Optional[torch.Tensor] = None            # int32 [B+1], prefill only
     workspace: Optional[torch.Tensor] = None
 
@@ -51,6 +53,10 @@ class MI355AttnBackend:
         self.page_size = model_runner.page_size
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._workspace: Optional[torch.Tensor] = None
+        self._plan_buf: Optional[torch.Tensor] = None
+        self._plan_key = None
+        # "planned": per-forward plan + stream-split kernel (default); "chunked": self-contained m355_decode_attn
+        self.decode_mode = os.environ.get("M355_DECODE_MODE", "planned")
         self._num_kv_heads_hint = getattr(getattr(model_runner, "kvcache", None), "head_num", None)
 
     # ---- metadata -------------------------------------------------------------------------------
@@ -69,6 +75,7 @@ class MI355AttnBackend:
             hkv = self._num_kv_heads_hint or batch.kvcache.head_num
             self.forward_metadata = ForwardMetadata(decode=True, max_seq_len=max(lens),
                                                     chunk_tokens=pick_decode_chunk(sum(lens), hkv))
+            self._plan_key = (batch, sum(lens))       # the plan itself needs the layer's head shape: built lazily
             return
         pre = getattr(batch, "prefix_lens_host", None)
         if pre is None:
@@ -101,6 +108,15 @@ class MI355AttnBackend:
         self._store_kv(k, v, layer, batch)
         k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
         B = q.shape[0]
+        if self.decode_mode == "planned":
+            Hq, Hkv, D = layer.num_heads, layer.num_kv_heads, layer.head_dim
+            if md.plan is None:                        # first layer of this forward: lay the token stream out once
+                cap = self._plan_key[1]
+                md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
+                                          self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
+                self._plan_buf = md.plan.buf
+            ws = self._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), q.device)
+            return ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws)
         ws = self._ws(ops.decode_workspace_bytes(B, layer.num_heads, layer.head_dim, md.max_seq_len, md.chunk_tokens),
                       q.device)
         return ops.decode_attn(q.reshape(B, layer.num_heads * layer.head_dim), k_pool, v_pool,

@@ -125,6 +125,65 @@ def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, pag
     return out
 
 
+class DecodePlan:
+    """Per-forward decode plan (device buffer + the sizes it was built for)."""
+
+    def __init__(self, buf, B, Hkv, D, G, capacity):
+        self.buf, self.B, self.Hkv, self.D, self.G, self.capacity = buf, B, Hkv, D, G, capacity
+
+
+def decode_plan(page_table: torch.Tensor, page_table_ids: torch.Tensor, seq_lens: torch.Tensor, page_size: int,
+                num_heads: int, num_kv_heads: int, head_dim: int, token_capacity: int,
+                buf: torch.Tensor | None = None) -> DecodePlan:
+    """Build the per-forward decode plan on the device (no host sync).  token_capacity >= sum(seq_lens)."""
+    lib = _lib.load()
+    for n, t in (("page_table", page_table), ("page_table_ids", page_table_ids), ("seq_lens", seq_lens)):
+        require_cuda(t, n)
+    assert page_table.dtype == torch.int32 and page_table_ids.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    B = seq_lens.numel()
+    G = num_heads // num_kv_heads
+    need = int(lib.m355_decode_plan_bytes(B, num_kv_heads, head_dim, G, token_capacity))
+    if buf is None or buf.numel() * buf.element_size() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=seq_lens.device)
+    check(lib.m355_decode_plan(seq_lens.data_ptr(), page_table_ids.data_ptr(), page_table.data_ptr(),
+                               page_table.stride(0), B, page_size, num_kv_heads, head_dim, G, token_capacity,
+                               buf.data_ptr(), buf.numel() * buf.element_size(), current_stream()), "m355_decode_plan")
+    return DecodePlan(buf, B, num_kv_heads, head_dim, G, token_capacity)
+
+
+def decode_planned_workspace_bytes(B: int, Hq: int, Hkv: int, D: int, token_capacity: int) -> int:
+    return int(_lib.load().m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity))
+
+
+def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, plan: DecodePlan,
+                        num_heads: int, scale: float | None = None, workspace: torch.Tensor | None = None,
+                        out: torch.Tensor | None = None) -> torch.Tensor:
+    """Planned paged decode attention (same result as decode_attn)."""
+    lib = _lib.load()
+    for n, t in (("q", q), ("k_pool", k_pool), ("v_pool", v_pool)):
+        require_cuda(t, n)
+    S, Hkv, D = k_pool.shape
+    B, Hq = q.shape[0], num_heads
+    if (B, Hkv, D, Hq // Hkv) != (plan.B, plan.Hkv, plan.D, plan.G):
+        raise _lib.MI355AttnError("decode_attn_planned: plan was built for a different batch or head shape")
+    q2 = q.view(B, Hq * D)
+    if q2.stride(1) != 1:
+        q2 = q2.contiguous()
+    if out is None:
+        out = torch.empty((B, Hq * D), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = float(D) ** -0.5
+    need = decode_planned_workspace_bytes(B, Hq, Hkv, D, plan.capacity)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    check(lib.m355_decode_attn_planned(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(),
+                                       plan.buf.data_ptr(), out.data_ptr(), out.stride(0), B, Hq, Hkv, D, scale,
+                                       plan.capacity, workspace.data_ptr(),
+                                       workspace.numel() * workspace.element_size(), dtype_code(q.dtype),
+                                       current_stream()), "m355_decode_attn_planned")
+    return out
+
+
 def prefill_workspace_bytes(T: int, Hq: int, D: int, max_seq_len: int) -> int:
     return int(_lib.load().m355_prefill_workspace_bytes(T, Hq, D, max_seq_len))
 

@@ -163,6 +163,71 @@ def test_decode_attn_split_and_merge(Hq, Hkv, D, ps):
         o = ops.decode_attn(dq, dk, dv, dt, dr, dl, ps, Hq, max(lens), chunk_tokens=chunk)
         torch.cuda.synchronize()
         np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"chunk={chunk}")
+    for cap in (sum(lens), sum(lens) + 1000):
+        plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, cap)
+        o = ops.decode_attn_planned(dq, dk, dv, plan, Hq)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"planned cap={cap}")
+
+
+def _gpu_decode_reference(q, kp, vp, table, rows, lens, ps, Hq):
+    """torch fp32 on the GPU, one request at a time, same gather as the reference backend."""
+    B = len(lens)
+    Hkv, D = kp.shape[1], kp.shape[2]
+    ref = torch.empty((B, Hq, D), device=q.device)
+    for b, l in enumerate(lens):
+        pos = torch.arange(l, device=q.device)
+        slots = table[rows[b], pos // ps].long() * ps + pos % ps
+        k = kp[slots].float().repeat_interleave(Hq // Hkv, dim=1)
+        v = vp[slots].float().repeat_interleave(Hq // Hkv, dim=1)
+        s = torch.einsum("hd,lhd->hl", q[b].view(Hq, D).float(), k) * D ** -0.5
+        ref[b] = torch.einsum("hl,lhd->hd", torch.softmax(s, dim=-1), v)
+    return ref.view(B, -1)
+
+
+def test_decode_planned_many_tiny_requests():
+    """More requests inside one range than a pass stages (kMaxPieces): ranges are walked in several passes."""
+    m, ops = _mods()
+    Hq, Hkv, D, ps = 8, 2, 64, 4
+    rng = np.random.default_rng(3)
+    lens = [int(x) for x in rng.integers(1, 6, size=700)]
+    B = len(lens)
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, lens, seed=11)
+    q = (torch.randn((B, Hq * D), generator=torch.Generator().manual_seed(4)) * 2).to(torch.bfloat16)
+    dq, dk, dv = q.to(DEV), kp.to(DEV), vp.to(DEV)
+    dt, dr, dl = torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV)
+    ref = _gpu_decode_reference(dq, dk, dv, dt, dr, lens, ps, Hq)
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    o = ops.decode_attn_planned(dq, dk, dv, plan, Hq)
+    assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    o2 = ops.decode_attn(dq, dk, dv, dt, dr, dl, ps, Hq, max(lens))
+    assert torch.allclose(o2.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+
+
+def test_decode_planned_more_ranges_than_waves():
+    """A token stream longer than waves x 1024 tokens: every wave walks several ranges."""
+    m, ops = _mods()
+    Hq, Hkv, D, ps = 8, 8, 64, 16
+    lens = [70001, 64000, 59999, 61234, 66000, 63000, 58000, 65536]       # 507 770 tokens > 384 * 1024
+    B = len(lens)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    npages = sum(-(-l // ps) for l in lens)
+    perm = torch.randperm(npages, generator=torch.Generator().manual_seed(1)).to(torch.int32)
+    W = max(-(-l // ps) for l in lens)
+    table = torch.zeros((B, W), dtype=torch.int32)
+    off = 0
+    for b, l in enumerate(lens):
+        n = -(-l // ps)
+        table[b, :n] = perm[off:off + n]
+        off += n
+    kp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)
+    vp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)
+    q = (torch.randn((B, Hq * D), generator=g, device=DEV) * 3).to(torch.bfloat16)
+    dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
+    ref = _gpu_decode_reference(q, kp, vp, dt, list(range(B)), lens, ps, Hq)
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    o = ops.decode_attn_planned(q, kp, vp, plan, Hq)
+    assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
 
 
 def test_decode_attn_softmax_spike():
@@ -180,6 +245,10 @@ def test_decode_attn_softmax_spike():
         o = ops.decode_attn(q.to(DEV), kp.to(DEV), vp.to(DEV), torch.from_numpy(table).to(DEV),
                             torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV), ps, Hq, 500, chunk_tokens=chunk)
         np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    plan = ops.decode_plan(torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV),
+                           ps, Hq, Hkv, D, 500)
+    o = ops.decode_attn_planned(q.to(DEV), kp.to(DEV), vp.to(DEV), plan, Hq)
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
 
 
 @pytest.mark.parametrize("Hq,Hkv,D,ps", [(32, 8, 64, 16), (32, 8, 128, 16), (8, 1, 128, 1), (16, 4, 128, 256)])
@@ -231,6 +300,7 @@ def test_decode_cfg2_full_size_properties():
     q = torch.randn((B, Hq * D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
     dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
     outs = [ops.decode_attn(q, kp, vp, dt, dr, dl, ps, Hq, max(lens), chunk_tokens=c).float() for c in (0, 128, 512)]
+    outs.append(ops.decode_attn_planned(q, kp, vp, ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens)), Hq).float())
     for o in outs[1:]:
         assert torch.allclose(o, outs[0], rtol=BF16_RTOL, atol=BF16_ATOL)
     # torch fp32 reference on the GPU, one sequence at a time (same gather as the reference backend)

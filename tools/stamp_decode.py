@@ -16,6 +16,10 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "mini-sglang_amd"))
 os.environ.setdefault("M355_DECODE_VARIANT", "17")
+STREAM = os.environ.get("STAMP_STREAM") == "1"
+if STREAM:
+    os.environ["M355_STREAM_VARIANT"] = "0"
+    os.environ["M355_STREAM_STAMP"] = "1"
 import mi355_attn as m  # noqa: E402
 from mi355_attn import _lib, ops  # noqa: E402
 
@@ -38,16 +42,21 @@ batch.prepare_for_prefill()
 q = torch.randn((B, Hq * D), device=dev).to(torch.bfloat16)
 max_len = max(lens)
 max_splits = -(-max_len // chunk)
-nblocks = B * Hkv * max_splits
+nblocks = 256 * 8 if STREAM else B * Hkv * max_splits
 stamps = torch.zeros((nblocks, 8), dtype=torch.int64, device=dev)
 lib = _lib.load()
-lib.m355dbg_set_stamp_buffer.argtypes = [ctypes.c_void_p]
-assert lib.m355dbg_set_stamp_buffer(stamps.data_ptr()) == 0
+setter = lib.m355dbg_set_stream_stamp_buffer if STREAM else lib.m355dbg_set_stamp_buffer
+setter.argtypes = [ctypes.c_void_p]
+assert setter(stamps.data_ptr()) == 0
+plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens)) if STREAM else None
 ws = torch.empty(ops.decode_workspace_bytes(B, Hq, D, max_len, chunk), dtype=torch.uint8, device=dev)
 
 
 def run(layer):
     kp, vp = kv.get_kv_cache(layer)
+    if STREAM:
+        ops.decode_attn_planned(q, kp, vp, plan, Hq)
+        return
     ops.decode_attn(q, kp, vp, pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, max_len,
                     chunk_tokens=chunk, workspace=ws)
 
@@ -67,7 +76,7 @@ print(f"chunk {chunk}: blocks {nblocks}, live {live.sum()}, dead {dead.sum()}")
 us = lambda x: x * 0.01
 a = s[live]
 print(f"entry time   (us after first wave): median {us(np.median(a[:,0]-t0)):.2f}  p95 {us(np.percentile(a[:,0]-t0,95)):.2f}  max {us((a[:,0]-t0).max()):.2f}")
-names = ["lens/row", "slots+q", "first tile", "loop", "finish+stores"]
+names = ["record+slots", "(pass start)", "tiles issued+q staged", "loop", "stores retired"] if STREAM else ["lens/row", "slots+q", "first tile", "loop", "finish+stores"]
 for k in range(5):
     d = a[:, k + 1] - a[:, k]
     print(f"phase {names[k]:14s}: median {us(np.median(d)):.2f} us  p95 {us(np.percentile(d,95)):.2f}  max {us(d.max()):.2f}")
@@ -78,3 +87,21 @@ if dead.sum():
 # how the finish time is distributed
 end = np.sort(a[:, 5] - t0)
 print("wave end-time percentiles (us):", [round(us(np.percentile(end, p)), 2) for p in (5, 25, 50, 75, 95, 100)])
+if STREAM:
+    hdr = plan.buf.view(torch.int32)[:8].cpu().numpy()
+    total, R, nr = int(hdr[0]), int(hdr[1]), int(hdr[4])
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    nwh = 256 * 8 // Hkv
+    loop = (a[:, 4] - a[:, 3]) * 0.01
+    life = (a[:, 5] - a[:, 0]) * 0.01
+    w = np.arange(nblocks) // Hkv
+    npieces = np.array([np.searchsorted(cum, min((x + 1) * R, total), side="left") - np.searchsorted(cum, x * R, side="right") + 1 for x in w])
+    print(f"R={R} ranges={nr} total={total}")
+    for k in sorted(set(npieces)):
+        sel = npieces == k
+        print(f"pieces={k}: waves {sel.sum():5d}  loop median {np.median(loop[sel]):.2f}  p95 {np.percentile(loop[sel],95):.2f}")
+    for x in range(8):
+        sel = (np.arange(nblocks) % 8) == x
+        print(f"blockIdx%8={x}: loop median {np.median(loop[sel]):.2f} p95 {np.percentile(loop[sel],95):.2f} life median {np.median(life[sel]):.2f}")
+    # last waves of the stream have a short range
+    print("loop time of the 16 slowest waves:", np.sort(loop)[-16:].round(1), "their w:", w[np.argsort(loop)[-16:]])
