@@ -12,6 +12,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWave = 64;
 constexpr float kLog2e = 1.4426950408889634f;
@@ -52,6 +54,28 @@ __device__ __forceinline__ float group_sum(float x) {
     x = dpp_add<kDppHalfMirror>(x);
     if constexpr (LANES == 16) x = dpp_add<kDppMirror>(x);
     return x;
+}
+
+// (own, partner) of a value across lanes l and l ^ MASK, MASK in {8, 16, 32}, in VALU only (no LDS round trip):
+// DPP row rotate for 8, v_permlane16_swap / v_permlane32_swap for 16 / 32.  For the swaps which of a / b is "own"
+// depends on the lane, so callers must use them symmetrically - and the same way for every value of one state.
+template <int MASK>
+__device__ __forceinline__ void lane_pair(float x, float& a, float& b) {
+    const unsigned ux = __builtin_bit_cast(unsigned, x);
+    if constexpr (MASK == 8) {
+        a = x;
+        b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, (int)ux, 0x128 /*row_ror:8*/, 0xF, 0xF, true));
+    } else if constexpr (MASK == 16) {
+        // inline asm: with both inputs equal, hipcc (ROCm 7.2) folds the builtin's two results into one register
+        unsigned ua = ux, ub = ux;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ua), "+v"(ub));
+        a = __builtin_bit_cast(float, ua); b = __builtin_bit_cast(float, ub);
+    } else {
+        static_assert(MASK == 32, "lane_pair: unsupported distance");
+        unsigned ua = ux, ub = ux;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ua), "+v"(ub));
+        a = __builtin_bit_cast(float, ua); b = __builtin_bit_cast(float, ub);
+    }
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? M355_OK : M355_ERR_LAUNCH; }
