@@ -194,6 +194,8 @@ def main():
     bytes_launch = attn_bytes_per_layer(lens_now, Hq, Hkv, D, ps)
     achieved = bytes_launch / (us_per_launch * 1e-6) / 1e9
 
+    traffic = pmc_traffic(planned) if tp == 1 and not args.heads and not args.copies else None
+
     cpu = None
     if rank == 0 and tp == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(kv, pm, batch, q, lens_now, Hq, Hkv, D, ps)
@@ -212,13 +214,33 @@ def main():
             "roofline": {"kernel": "m355::decode_stream_kernel (+ stream_merge_kernel)" if planned
                          else "m355::decode_split_kernel (+ decode_merge_kernel)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "us_per_launch": round(us_per_launch, 3), "algorithmic_bytes_per_launch": bytes_launch},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if tp > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(planned: bool):
+    """HBM bytes per attention launch (main + merge kernel) from the newest committed PMC summary of this same
+    command (profiles/rNN_pmc_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE and
+    WRITE_SIZE passes, already corrected per MI355X_MICROARCH.md).  None when no summary covers the kernels."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        kernels = json.load(f)["kernels"]
+    want = ("decode_stream_kernel", "stream_merge_kernel") if planned else ("decode_split_kernel", "decode_merge_kernel")
+    tot = 0
+    for w in want:
+        hit = [e["hbm_bytes_per_launch"] for k, e in kernels.items() if w in k]
+        if not hit:
+            return None
+        tot += hit[0]
+    return tot
 
 
 def cpu_baseline(kv, pm, batch, q, lens, Hq, Hkv, D, ps):
