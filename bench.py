@@ -88,9 +88,11 @@ def main():
     import mi355_attn as m
     from mi355_attn import ops
 
+    from mi355_attn.tp import all_reduce_rows, shard_heads
+
     tp = world
-    Hq, Hkv, D, L, hidden = MODEL["Hq"] // tp, MODEL["Hkv"] // tp, MODEL["D"], MODEL["layers"], MODEL["hidden"]
-    assert Hkv >= 1, "tp > num_kv_heads is not a reference configuration"
+    shard = shard_heads(MODEL["Hq"], MODEL["Hkv"], MODEL["D"], tp, rank)    # refuses tp > num_kv_heads
+    Hq, Hkv, D, L, hidden = shard.num_heads, shard.num_kv_heads, MODEL["D"], MODEL["layers"], MODEL["hidden"]
     if args.heads:
         Hq, Hkv, D = (int(x) for x in args.heads.split(","))
     ps = PAGE_SIZE
@@ -133,7 +135,7 @@ def main():
         for layer in layers:
             o = layer(q, k, v, batch)
             if tp > 1:
-                dist.all_reduce(red)                 # the o_proj row-parallel reduction (layers/linear.py:231)
+                all_reduce_rows(red)                 # the o_proj row-parallel reduction (layers/linear.py:231)
         return o
 
     def fence():

@@ -9,6 +9,7 @@ from .batch import Batch, Mode, Req, SamplingParams
 from .kvcache import KVCache
 from .page_manager import PageManager
 from .radix_cache import PagedRadixCache
+from .tp import HeadShard, all_reduce_rows, shard_heads
 
 __all__ = ["Attention", "MI355AttnBackend", "Batch", "Mode", "Req", "SamplingParams", "KVCache", "PageManager",
-           "PagedRadixCache"]
+           "PagedRadixCache", "HeadShard", "shard_heads", "all_reduce_rows"]
