@@ -139,6 +139,22 @@ int m355_prefill_attn(const void *q, int64_t q_row_stride, const void *k_pool, c
                       int32_t max_seq_len_hint, int32_t Hq, int32_t Hkv, int32_t D, int32_t page_size,
                       float scale, void *workspace, int64_t workspace_bytes, int32_t dtype, void *stream);
 
+/* Rotary embedding fused with the KV slot write (the step before the path).  Replaces
+ * RotaryEmbedding.forward (layers/rotary_embedding.py:65-93; formula :8-18, neox style over the whole head:
+ * y[i] = x[i]*cos - x[i+D/2]*sin, y[i+D/2] = x[i+D/2]*cos + x[i]*sin in fp32, cast back to bf16) as called at
+ * models/llama.py:135, and - when k_pool is not NULL - also KVCache.write_kv (memory/kvcache.py:69-79) for the same
+ * tokens, so the rotated k row is written to its slot without being re-read.
+ *   q [T, Hq*D], k [T, Hkv*D]: rotated IN PLACE (row strides in elements, multiples of 8, 16-byte aligned);
+ *   cos_sin_cache: fp32 [max_position, D], row p = cos(p*inv_freq[0..D/2)) | sin(...) (rotary_embedding.py:54-63);
+ *   positions int64 [T] (clamped into [0, max_position));
+ *   k_pool / v_pool [S, Hkv, D], v [T, Hkv*D], loc int64 [T]: as m355_kv_store; pass k_pool = NULL for rope only.
+ * No FMA contraction: bit-identical to the formula evaluated in fp32 op by op.  Parity with the sgl_kernel CUDA
+ * kernel the reference actually calls is unpinned (wheel not available). */
+int m355_rope_kv_store(void *q, int64_t q_row_stride, void *k, int64_t k_row_stride, const void *v,
+                       int64_t v_row_stride, const int64_t *positions, const float *cos_sin_cache,
+                       int64_t max_position, void *k_pool, void *v_pool, const int64_t *loc, int32_t T,
+                       int32_t Hq, int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,9 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_int32,
                                     c_void_p]),
+    "m355_rope_kv_store": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     c_int64, c_int32, c_void_p]),
 }
 
 _lib = None

@@ -221,3 +221,37 @@ def prefill_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, pa
                                 out.stride(0), B, T, max_extend_len, max_seq_len, Hq, Hkv, D, page_size, scale,
                                 _ptr(workspace), ws_bytes, dtype_code(q.dtype), current_stream()), "m355_prefill_attn")
     return out
+
+
+def rope_kv_store(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, head_dim: int, cos_sin_cache: torch.Tensor,
+                  v: torch.Tensor = None, k_pool: torch.Tensor = None, v_pool: torch.Tensor = None,
+                  loc: torch.Tensor = None) -> None:
+    """Neox rotary embedding on q [T, Hq*D] and k [T, Hkv*D] IN PLACE (layers/rotary_embedding.py:8-18, 65-93) and,
+    when pools are given, the slot write of the rotated k and of v in the same launch (memory/kvcache.py:69-79).
+    cos_sin_cache: fp32 [max_position, D] (cos | sin)."""
+    lib = _lib.load()
+    store = k_pool is not None
+    ts = [("positions", positions), ("q", q), ("k", k), ("cos_sin_cache", cos_sin_cache)]
+    if store:
+        ts += [("v", v), ("k_pool", k_pool), ("v_pool", v_pool), ("loc", loc)]
+    for n, t in ts:
+        require_cuda(t, n)
+    T = positions.numel()
+    D = head_dim
+    if q.dim() != 2 or k.dim() != 2 or (T and (q.stride(1) != 1 or k.stride(1) != 1)):
+        raise _lib.MI355AttnError("rope_kv_store: q and k must be [T, heads*D] with inner stride 1")
+    Hq, Hkv = q.shape[1] // D, k.shape[1] // D
+    if positions.dtype != torch.int64 or cos_sin_cache.dtype != torch.float32 or cos_sin_cache.shape[1] != D \
+            or not cos_sin_cache.is_contiguous() or not positions.is_contiguous():
+        raise _lib.MI355AttnError("rope_kv_store: positions int64, cos_sin_cache contiguous fp32 [max_position, D]")
+    S = 0
+    if store:
+        S = k_pool.shape[0]
+        if v.dim() != 2 or (T and v.stride(1) != 1) or loc.dtype != torch.int64 or not loc.is_contiguous() \
+                or not (k_pool.is_contiguous() and v_pool.is_contiguous()) or k_pool.dtype != k.dtype:
+            raise _lib.MI355AttnError("rope_kv_store: v [T, Hkv*D] inner stride 1, loc int64, contiguous pools of k's dtype")
+    check(lib.m355_rope_kv_store(q.data_ptr(), q.stride(0) if T else Hq * D, k.data_ptr(), k.stride(0) if T else Hkv * D,
+                                 _ptr(v) if store else None, (v.stride(0) if T else Hkv * D) if store else 0,
+                                 positions.data_ptr(), cos_sin_cache.data_ptr(), cos_sin_cache.shape[0],
+                                 _ptr(k_pool), _ptr(v_pool), _ptr(loc) if store else None, T, Hq, Hkv, D, S,
+                                 dtype_code(q.dtype), current_stream()), "m355_rope_kv_store")

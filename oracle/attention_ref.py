@@ -160,3 +160,27 @@ def rope_neox_ref(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, hea
         return torch.cat((o1, o2), dim=-1).to(x.dtype).reshape(x.shape)
 
     return rot(q), rot(k)
+
+
+def rope_inv_freq_ref(rotary_dim: int, base: float, rope_scaling: dict | None = None) -> torch.Tensor:
+    """Inverse frequencies (reference layers/rotary_embedding.py:45-53) with the Llama-3 rescaling of
+    Llama3RotaryEmbedding._compute_inv_freq (:116-137) when ``rope_scaling`` has rope_type 'llama3'."""
+    inv = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))
+    if rope_scaling is None:
+        return inv
+    factor = rope_scaling["factor"]
+    low, high = rope_scaling["low_freq_factor"], rope_scaling["high_freq_factor"]
+    orig = rope_scaling["original_max_position_embeddings"]
+    low_wl, high_wl = orig / low, orig / high
+    wl = 2 * math.pi / inv
+    smooth = (orig / wl - low) / (high - low) if low != high else 0
+    mid = (1 - smooth) * inv / factor + smooth * inv
+    return torch.where(wl < high_wl, inv, torch.where(wl > low_wl, inv / factor, mid))
+
+
+def rope_cache_ref(rotary_dim: int, max_position: int, base: float, rope_scaling: dict | None = None) -> torch.Tensor:
+    """fp32 [max_position, rotary_dim] cos|sin cache (reference layers/rotary_embedding.py:54-63)."""
+    inv = rope_inv_freq_ref(rotary_dim, base, rope_scaling)
+    t = torch.arange(max_position, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, inv)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1)
