@@ -78,6 +78,23 @@ __device__ __forceinline__ void lane_pair(float x, float& a, float& b) {
     }
 }
 
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS at (lds_dst + 16*lane), no VGPR round trip.
+// hipcc does not count these loads in its own s_waitcnt bookkeeping: callers wait with wait_vmcnt<N>() themselves.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+template <int N, int STEP>
+__device__ __forceinline__ void wait_tiles_younger(int younger) {
+    // wait until all but `younger` tiles (STEP DMA instructions each) of this wave have landed
+    if constexpr (N == 0) { wait_vmcnt<0>(); }
+    else { if (younger >= N) wait_vmcnt<N * STEP>(); else wait_tiles_younger<N - 1, STEP>(younger); }
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? M355_OK : M355_ERR_LAUNCH; }
 
 }  // namespace m355

@@ -297,20 +297,6 @@ __global__ __launch_bounds__(64, W) void decode_split_kernel(const DecodeParams 
 // every LDS read otherwise), so the kernel issues no other vector-memory operation inside the loop, and every
 // load hipcc does count (page table, q) is forced to retire before the first DMA.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
-
-template <int N, int STEP>
-__device__ __forceinline__ void wait_tiles_younger(int younger) {
-    // wait until all but `younger` tiles (STEP DMA instructions each) of this wave have landed
-    if constexpr (N == 0) { wait_vmcnt<0>(); }
-    else { if (younger >= N) wait_vmcnt<N * STEP>(); else wait_tiles_younger<N - 1, STEP>(younger); }
-}
 
 template <int D, int G, int U, int R, int W, bool POW2>
 __global__ __launch_bounds__(64, W) void decode_split_lds_kernel(const DecodeParams p) {

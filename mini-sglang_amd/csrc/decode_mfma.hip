@@ -1,0 +1,366 @@
+// Planned paged decode attention on the matrix cores (gfx950).
+//
+// Same plan, same partial format and same merge kernel as decode_stream.hip; what changes is the inner product
+// engine.  The VALU kernel spends ~200 vector instructions per 16 tokens (dot2 + DPP reductions + per-lane online
+// softmax + FMA accumulation) and measured "compute only" it takes as long as streaming the KV bytes does.  Here a
+// wave consumes 32-token stages with v_mfma_f32_16x16x32_bf16:
+//
+//   K, V rows      HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), R stages deep, whole 2*D-byte rows
+//                  (coalesced), XOR-swizzled by choosing which 16-byte chunk each lane fetches
+//   S^T[tok, q]  = K[32 x D] . Q^T[D x 16]     2 x D/32 MFMAs; K fragments are ds_read_b128 rows, Q^T fragments stay in
+//                  registers (columns >= G are zero).  A lane then owns ONE q head (column lane&15) and 4+4 tokens
+//   softmax        one running max per q head shared by the four 16-lane groups (two permlane swaps), exp2 on 8 values,
+//                  the accumulator is rescaled only when some max moved
+//   O^T[d, q]   += V^T[D x 32] . P^T[32 x 16]   D/16 MFMAs; P^T is the S^T accumulator re-packed to bf16 in registers
+//                  (its k index is the lane group and register, the V^T fragments use the same token order), V^T
+//                  fragments are ds_read_b64_tr_b16 transposed reads of the row-major V stage
+//
+// ~60 vector instructions and 8 MFMAs per 32 tokens instead of ~400.  Token order inside a stage for the k index of
+// the second product: lane group kg (lane>>4), element j -> token 4*kg + j (j < 4), 16 + 4*kg + (j-4) (j >= 4).
+//
+// LDS per wave: R stages of 64*D bytes (K then V), q rows of kQP pieces, the range's slots, the range record.
+// All loads inside the loop are LDS-DMA issued and waited for with hand-counted vmcnt (see common.h).
+#include <stdlib.h>
+
+#include "stream_plan.h"
+
+namespace m355 {
+
+constexpr int kQP = 4;                          // pieces whose q rows are staged in LDS at a time
+constexpr int kLdsPerCU = 160 * 1024;
+
+template <int D>
+struct MG {
+    static constexpr int C = D / 8;             // 16-byte chunks per K/V row of one head
+    static constexpr int ROWB = 2 * D;          // bytes per row
+    static constexpr int RPI = 64 / C;          // rows one DMA instruction brings (1 KiB)
+    static constexpr int NI = 32 / RPI;         // DMA instructions per 32-row tile
+    static constexpr int TILEB = 32 * ROWB;     // K (or V) tile bytes
+    static constexpr int STAGEB = 2 * TILEB;
+    static constexpr int KS = D / 32;           // k-steps of S^T = K Q^T
+    static constexpr int DT = D / 16;           // d-tiles of O^T
+    static constexpr int SPAN = 16 / C;         // rows per 256-byte bank span
+    // 16-byte chunk ch of row `row` lives at chunk position ch ^ s(row) of that row: conflict-free ds_read_b128 row
+    // reads of K (16 rows, one chunk column) and conflict-free transposed reads of V (8 rows x 2 chunks per half wave)
+    __host__ __device__ static constexpr int sK(int row) { return (row / SPAN) % C; }
+    __host__ __device__ static constexpr int sV(int row) { return ((row / SPAN) % (C / 2)) * 2; }
+};
+
+__host__ __device__ inline int mfma_lds_bytes(int D, int G, int R, int slots_cap) {
+    return R * 64 * D * 2 + kQP * G * 2 * D + slots_cap * 4 + 64 * 4;
+}
+
+template <int D, int G, int R, bool STAMP>
+__global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, const int slots_cap) {
+    using M = MG<D>;
+    static_assert(G <= 16, "q heads of a group sit in the 16 columns of one MFMA");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+    uint8_t* const ringp = smem;
+    uint8_t* const qsp = smem + R * M::STAGEB;
+    int32_t* const slots = reinterpret_cast<int32_t*>(qsp + kQP * G * M::ROWB);
+    int32_t* const rec = slots + slots_cap;
+    int32_t* const pc = rec + 4;                         // piece k: pc[4k .. 4k+3] = {request, start, length, partial index}
+
+    sstamp<STAMP>(p, 0);
+    const int lane = threadIdx.x;
+    const int n = lane & 15;                             // q column / K row / d column, by operand
+    const int kg = lane >> 4;                            // 16-lane group = k sub-block
+    const int w = blockIdx.x / p.Hkv;
+    const int h = blockIdx.x % p.Hkv;
+    const int32_t* plan = p.plan;
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)h * M::ROWB;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)h * M::ROWB;
+    const int64_t row_bytes = p.row_elems * 2;
+    const uint32_t ring0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ringp);
+
+    // per-lane constants
+    const int drow = lane / M::C, dch = lane % M::C;     // DMA: row inside the instruction, chunk position
+    int koff[M::NI], voff[M::NI];
+#pragma unroll
+    for (int i = 0; i < M::NI; ++i) {
+        const int row = i * M::RPI + drow;
+        koff[i] = 16 * (dch ^ M::sK(row));
+        voff[i] = 16 * (dch ^ M::sV(row));
+    }
+    const int ka0 = n * M::ROWB + 16 * (kg ^ M::sK(n));  // K fragment (row n [+16], k-step s): ka0 ^ 64 s
+    const int vrow = 4 * kg + (n >> 2);
+    const int va0 = vrow * M::ROWB + 16 * (M::sV(vrow) | ((n & 3) >> 1)) + 8 * (n & 1);   // V^T block (d-tile dt): va0 ^ 32 dt
+    const int qa0 = (n < G ? n : 0) * M::ROWB + 16 * kg;                                  // Q^T fragment (k-step s): + 64 s
+
+    f32x4 O[M::DT];
+    float m_run = kNegBig, l_run = 0.f;
+    bf16x8 qf[M::KS];
+
+    auto run_pass = [&](const int p0, const int np) {
+        // ---- q rows of the pass's pieces -> LDS (ordinary loads: retired before the first counted DMA)
+        for (int i = lane; i < np * G * M::C; i += kWave) {
+            const int k = i / (G * M::C), c = i - k * (G * M::C);
+            *reinterpret_cast<u32x4*>(qsp + i * 16) =
+                *reinterpret_cast<const u32x4*>(p.q + (int64_t)pc[(p0 + k) * 4] * p.q_stride + (int64_t)h * G * D + c * 8);
+        }
+        __syncthreads();
+        wait_vmcnt<0>();
+
+        int lk = 0, lit = 0, ck = 0, cit = 0, issued = 0, consumed = 0;
+        int l_start = __builtin_amdgcn_readfirstlane(pc[p0 * 4 + 1]);
+        int l_len = __builtin_amdgcn_readfirstlane(pc[p0 * 4 + 2]);
+        int c_len = l_len;
+
+        auto issue = [&](const int RS) {                  // RS: ring slot, a constant after unrolling
+            const uint32_t sbase = ring0 + RS * M::STAGEB;
+#pragma unroll
+            for (int i = 0; i < M::NI; ++i) {
+                int tt = lit * 32 + i * M::RPI + drow;
+                tt = tt < l_len ? tt : l_len - 1;         // clamp: rows past the piece are masked in the scores
+                const int64_t ro = (int64_t)slots[l_start + tt] * row_bytes;
+                glds16(kbase + ro + koff[i], sbase + 1024 * i);
+                glds16(vbase + ro + voff[i], sbase + M::TILEB + 1024 * i);
+            }
+            ++issued;
+            ++lit;
+            if (lit * 32 >= l_len) {
+                ++lk; lit = 0;
+                if (lk < np) {
+                    l_start = __builtin_amdgcn_readfirstlane(pc[(p0 + lk) * 4 + 1]);
+                    l_len = __builtin_amdgcn_readfirstlane(pc[(p0 + lk) * 4 + 2]);
+                }
+            }
+        };
+        auto begin_piece = [&]() {
+#pragma unroll
+            for (int s = 0; s < M::KS; ++s) {
+                u32x4 t = *reinterpret_cast<const u32x4*>(qsp + ck * (G * M::ROWB) + qa0 + 64 * s);
+                if (n >= G) t = u32x4{0u, 0u, 0u, 0u};
+                qf[s] = __builtin_bit_cast(bf16x8, t);
+            }
+            m_run = kNegBig; l_run = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < M::DT; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto end_piece = [&]() {
+            float a, b;
+            lane_pair<16>(l_run, a, b);
+            float l = a + b;
+            lane_pair<32>(l, a, b);
+            l = a + b;
+            const int bq = pc[(p0 + ck) * 4 + 0];
+            const int pidx = pc[(p0 + ck) * 4 + 3];
+            if (n < G) {
+                if (pidx < 0) {                          // the piece is the whole request: final output
+                    const float inv = 1.f / l;
+                    uint16_t* op = p.out + (int64_t)bq * p.o_stride + (int64_t)(h * G + n) * D + 4 * kg;
+#pragma unroll
+                    for (int dt = 0; dt < M::DT; ++dt) {
+                        uint32_t w0 = pack_bf16(O[dt][0] * inv, O[dt][1] * inv), w1 = pack_bf16(O[dt][2] * inv, O[dt][3] * inv);
+                        *reinterpret_cast<uint2*>(op + 16 * dt) = make_uint2(w0, w1);
+                    }
+                } else {
+                    const int64_t idx = (int64_t)pidx * p.Hq + h * G + n;
+                    float* wo = p.ws_o + idx * D + 4 * kg;
+#pragma unroll
+                    for (int dt = 0; dt < M::DT; ++dt) *reinterpret_cast<f32x4*>(wo + 16 * dt) = O[dt];
+                    if (kg == 0) { p.ws_ml[idx * 2] = m_run; p.ws_ml[idx * 2 + 1] = l; }
+                }
+            }
+        };
+        auto consume = [&](const int RS) {
+            const uint8_t* st = ringp + RS * M::STAGEB;
+            if (cit == 0) begin_piece();
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < M::KS; ++s) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + (ka0 ^ (64 * s)));
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + 16 * M::ROWB + (ka0 ^ (64 * s)));
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[s], s1, 0, 0, 0);
+            }
+            const int rem = c_len - cit * 32;            // valid tokens of this stage
+            if (rem < 32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (4 * kg + r >= rem) s0[r] = kNegBig;
+                    if (16 + 4 * kg + r >= rem) s1[r] = kNegBig;
+                }
+            }
+            float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+            float a, b;
+            lane_pair<16>(mx, a, b);
+            mx = fmaxf(a, b);
+            lane_pair<32>(mx, a, b);
+            mx = fmaxf(a, b);
+            const float m_new = fmaxf(m_run, mx * p.scale_log2);
+            const float alpha = exp2_fast(m_run - m_new);
+            m_run = m_new;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = exp2_fast(fmaf(s0[r], p.scale_log2, -m_new));
+                s1[r] = exp2_fast(fmaf(s1[r], p.scale_log2, -m_new));
+                sum += s0[r] + s1[r];
+            }
+            l_run = fmaf(l_run, alpha, sum);
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int dt = 0; dt < M::DT; ++dt) O[dt] *= alpha;
+            }
+            const u32x4 pw = {pack_bf16(s0[0], s0[1]), pack_bf16(s0[2], s0[3]), pack_bf16(s1[0], s1[1]), pack_bf16(s1[2], s1[3])};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+            for (int dt = 0; dt < M::DT; ++dt) {
+                const uint8_t* va = st + M::TILEB + (va0 ^ (32 * dt));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)va);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)(va + 16 * M::ROWB));
+                const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), pf, O[dt], 0, 0, 0);
+            }
+            ++consumed;
+            ++cit;
+            if (cit * 32 >= c_len) {
+                end_piece();
+                ++ck; cit = 0;
+                if (ck < np) c_len = __builtin_amdgcn_readfirstlane(pc[(p0 + ck) * 4 + 2]);
+            }
+        };
+
+        sstamp<STAMP>(p, 2);
+        // ---- fill the ring, then: refill the slot consumed last, wait for the oldest stage, consume it
+#pragma unroll
+        for (int j = 0; j < R - 1; ++j)
+            if (lk < np) issue(j);
+        sstamp<STAMP>(p, 3);
+        while (ck < np) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (ck < np) {
+                    if (lk < np) issue((j + R - 1) % R);
+                    wait_tiles_younger<R - 1, 2 * M::NI>(issued - consumed - 1);
+                    consume(j);
+                }
+            }
+        }
+        __syncthreads();                                 // rec / q rows / slots are rewritten next
+    };
+
+    for (int r = w; r < p.max_ranges; r += p.nwh) {
+        // ---- the record and (speculatively) the first slots in one round of loads
+        const int32_t* grec = plan + p.off_rec + (int64_t)r * kRec;
+        const int32_t* gslots = plan + p.off_slots + (int64_t)r * kRMax;
+        int32_t rv = 0, sv[kSpec];
+        if (lane < kRec) rv = grec[lane];
+#pragma unroll
+        for (int k = 0; k < kSpec; ++k) sv[k] = gslots[lane + kWave * k];
+        if (lane < kRec) rec[lane] = rv;
+#pragma unroll
+        for (int k = 0; k < kSpec; ++k)
+            if (lane + kWave * k < slots_cap) slots[lane + kWave * k] = sv[k];
+        __syncthreads();
+        const int32_t nt = __builtin_amdgcn_readfirstlane(rec[0]);
+        const int32_t np_rec = __builtin_amdgcn_readfirstlane(rec[1]);
+        if (nt == 0) break;                              // past the last range
+        if (nt > kSpec * kWave) {
+            for (int i = kSpec * kWave + lane; i < nt && i < slots_cap; i += kWave) slots[i] = gslots[i];
+            __syncthreads();
+        }
+        sstamp<STAMP>(p, 1);
+        // pieces come from the record, or - more than kMaxPieces requests in the range - from scanning cum in rounds
+        const bool scanning = np_rec < 0;
+        const int32_t* cum = plan + p.off_cum;
+        const int32_t* pbase = plan + p.off_pbase;
+        const int32_t g0 = __builtin_amdgcn_readfirstlane(rec[3]);
+        const int32_t Rt = plan[1];
+        int b_next = __builtin_amdgcn_readfirstlane(rec[2]);
+        int32_t done = 0;
+        int np = np_rec;
+        do {
+            if (scanning) {
+                __syncthreads();
+                const int bb = b_next + lane;
+                int32_t cs = 0, ce = 0;
+                if (lane < kMaxPieces && bb < p.B) { cs = cum[bb]; ce = cum[bb + 1]; }
+                const int32_t lo = max(cs, g0 + done), hi = min(ce, g0 + nt);
+                const bool have = lane < kMaxPieces && bb < p.B && hi > lo;
+                const unsigned long long mask = __ballot(have);
+                np = __popcll(mask);
+                if (have) {
+                    const int k = __popcll(mask & ((1ull << lane) - 1));
+                    pc[k * 4 + 0] = bb;
+                    pc[k * 4 + 1] = lo - g0;
+                    pc[k * 4 + 2] = hi - lo;
+                    pc[k * 4 + 3] = (lo == cs && hi == ce) ? -1 : pbase[bb] + (r - cs / Rt);
+                }
+                const int last = 63 - __clzll(mask | 1ull);
+                done = __builtin_amdgcn_readfirstlane((np > 0 ? __shfl(hi, last) : g0 + nt) - g0);
+                b_next = __builtin_amdgcn_readfirstlane(np > 0 ? b_next + last + 1 : b_next + kMaxPieces);
+                __syncthreads();
+            }
+            for (int p0 = 0; p0 < np; p0 += kQP) run_pass(p0, min(kQP, np - p0));
+        } while (scanning && done < nt);
+    }
+    if constexpr (STAMP) { sstamp<STAMP>(p, 4); wait_vmcnt<0>(); sstamp<STAMP>(p, 5); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int cu_count() {
+    static int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+static int mfma_ring() {
+    static int v = [] { const char* e = getenv("M355_MFMA_RING"); const int x = e ? atoi(e) : 2; return x < 2 ? 2 : (x > 4 ? 4 : x); }();
+    return v;
+}
+static int mfma_max_wpc() {
+    static int v = [] { const char* e = getenv("M355_MFMA_WPC"); const int x = e ? atoi(e) : 8; return x < 1 ? 1 : (x > 8 ? 8 : x); }();
+    return v;
+}
+int mfma_rmin() { return 128; }                          // >= 4 stages per range
+
+// slots a wave stages = the longest range the plan can make for this capacity
+static int mfma_slots_cap(int nwh, int64_t cap) {
+    int64_t rt = (cap + nwh - 1) / nwh;
+    if (rt < mfma_rmin()) rt = mfma_rmin();
+    if (rt > kRMax) rt = kRMax;
+    return (int)((rt + 63) / 64 * 64);
+}
+
+int mfma_waves_per_cu(int Hkv, int D, int G, int64_t cap) {
+    const int R = mfma_ring();
+    for (int wpc = mfma_max_wpc(); wpc > 1; --wpc) {
+        int nwh = cu_count() * wpc / Hkv;
+        if (nwh < 1) nwh = 1;
+        if ((int64_t)mfma_lds_bytes(D, G, R, mfma_slots_cap(nwh, cap)) * wpc <= kLdsPerCU) return wpc;
+    }
+    return 1;
+}
+
+template <int D, int G>
+static int launch_mfma(const StreamParams& p, int64_t cap, hipStream_t st, bool stamp) {
+    const int R = mfma_ring();
+    const int slots_cap = mfma_slots_cap(p.nwh, cap);
+    const int lds = mfma_lds_bytes(D, G, R, slots_cap);
+    if (lds > 64 * 1024) return M355_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(p.Hkv * p.nwh)), block(64);
+#define M355_RING(RR) if (R == RR) { \
+        if (stamp) hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, true>), grid, block, lds, st, p, slots_cap); \
+        else hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, false>), grid, block, lds, st, p, slots_cap); }
+    M355_RING(2) M355_RING(3) M355_RING(4)
+#undef M355_RING
+    return M355_OK;
+}
+
+int launch_stream_mfma(const StreamParams& p, int D, int G, int64_t cap, hipStream_t st, bool stamp) {
+#define M355_CASE(DD, GG) if (D == DD && G == GG) return launch_mfma<DD, GG>(p, cap, st, stamp);
+    M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
+    M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)
+#undef M355_CASE
+    return M355_ERR_UNSUPPORTED;
+}
+
+}  // namespace m355

@@ -21,53 +21,11 @@
 // Algorithmic bytes are those of decode_attn.hip; the plan adds 4 bytes per token per forward.
 #include <stdlib.h>
 
-#include "common.h"
+#include "stream_plan.h"
 
 namespace m355 {
 
-constexpr int kRMax = 1024;                     // tokens per range (LDS slot staging: 4 KiB)
-constexpr int kMaxPieces = 8;                   // pieces a range record holds (more: the range is walked by scanning cum)
-constexpr int kRec = 4 + 4 * kMaxPieces + 4;    // ints per record: n, np|-1, b0, g0, pieces{b,start,len,pidx}, pad
-constexpr int kSpec = 5;                        // slots loaded per lane together with the record (5*64 = 320 tokens)
-constexpr int kHdrInts = 8;
-
-// Dev-only timing probe (tools/stamp_decode.py): s_memrealtime per wave at phase boundaries when enabled.
-__device__ unsigned long long* g_sstamp_buf = nullptr;
-template <bool ON>
-__device__ __forceinline__ void sstamp(int k) {
-    if constexpr (ON)
-        if (g_sstamp_buf && threadIdx.x == 0) g_sstamp_buf[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
-}
-
-// plan buffer (int32 words): hdr[8] | cum[B+1] | pbase[B+1] | rec[max_ranges][kRec] | slots[max_ranges][kRMax]
-struct PlanLayout {
-    int64_t cum, pbase, rec, slots, ints;
-    int32_t max_ranges;
-};
-__host__ __device__ inline PlanLayout plan_layout(int32_t B, int32_t nwh, int64_t cap) {
-    PlanLayout L;
-    L.max_ranges = (int32_t)(nwh + cap / kRMax + 2);
-    L.cum = kHdrInts;
-    L.pbase = L.cum + (B + 1);
-    L.rec = (L.pbase + (B + 1) + 3) & ~(int64_t)3;
-    L.slots = L.rec + (int64_t)L.max_ranges * kRec;
-    L.ints = L.slots + (int64_t)L.max_ranges * kRMax;
-    return L;
-}
-
-struct StreamParams {
-    const uint16_t* q;
-    const uint16_t* k_pool;
-    const uint16_t* v_pool;
-    const int32_t* plan;
-    uint16_t* out;
-    float* ws_o;    // [n_partials, Hq, D]
-    float* ws_ml;   // [n_partials, Hq, 2]
-    int64_t q_stride, o_stride, row_elems;
-    int64_t off_cum, off_pbase, off_rec, off_slots;
-    int32_t B, Hq, Hkv, nwh, max_ranges;
-    float scale_log2;
-};
+static unsigned long long* g_stream_stamps = nullptr;   // host copy of the dev-only stamp buffer pointer
 
 // ------------------------------------------------------------------------------------------------
 // plan kernels
@@ -256,12 +214,12 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
     int32_t* pc = rec + 4;
     u32x4* qs = reinterpret_cast<u32x4*>(lds + kRMax + 64);
 
-    sstamp<STAMP>(0);
+    sstamp<STAMP>(p, 0);
     const int lane = threadIdx.x;
     const int dchunk = lane % LPH;
     const int tsub = lane / LPH;
-    const int h = blockIdx.x % p.Hkv;
     const int w = blockIdx.x / p.Hkv;
+    const int h = (blockIdx.x + (p.rot ? w : 0)) % p.Hkv;      // rot: heads rotate over the XCDs from range to range
     const int32_t* plan = p.plan;
     const int64_t lane_off = (int64_t)h * D + dchunk * 8;
 
@@ -334,7 +292,7 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
         };
 
         // first K/V tiles go out before the q rows: both are one dependent level behind the record
-        sstamp<STAMP>(2);
+        sstamp<STAMP>(p, 2);
         u32x4 kb[NB][U], vb[NB][U];
 #pragma unroll
         for (int j = 0; j < NB - 1; ++j)
@@ -344,7 +302,7 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
             qs[i] = *reinterpret_cast<const u32x4*>(p.q + (int64_t)pc[k * 4] * p.q_stride + (int64_t)h * G * D + c * 8);
         }
         __syncthreads();
-        sstamp<STAMP>(3);
+        sstamp<STAMP>(p, 3);
         while (ck < np) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {               // j static: the NB register tiles rotate by name
@@ -386,7 +344,7 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
             for (int i = kSpec * kWave + lane; i < n; i += kWave) slots[i] = gslots[i];
             __syncthreads();
         }
-        sstamp<STAMP>(1);
+        sstamp<STAMP>(p, 1);
         if (np_rec >= 0) {
             run_pass(np_rec);
         } else {
@@ -421,7 +379,7 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
             }
         }
     }
-    if constexpr (STAMP) { sstamp<STAMP>(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sstamp<STAMP>(5); }
+    if constexpr (STAMP) { sstamp<STAMP>(p, 4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sstamp<STAMP>(p, 5); }
 }
 
 // One wave per (request, q head): combine the partials of requests cut by range boundaries.
@@ -493,24 +451,33 @@ static inline StreamShape stream_shape(int G) {
     }
     return v == 1 ? StreamShape{2, 4, 3} : StreamShape{2, 3, 3};
 }
-static inline int stream_nwh(int Hkv, int G) {
-    const int n = num_cus() * 4 * stream_shape(G).W / Hkv;
+// Which attention kernel consumes the plan: the MFMA kernel (decode_mfma.hip, default) or the VALU kernel above
+// (M355_STREAM_KERNEL=valu).  The plan's waves-per-head and shortest range follow the kernel.
+static bool use_mfma() {
+    static bool v = [] { const char* e = getenv("M355_STREAM_KERNEL"); return !(e && e[0] == 'v'); }();
+    return v;
+}
+static inline int stream_nwh(int Hkv, int D, int G, int64_t cap) {
+    const int wpc = use_mfma() ? mfma_waves_per_cu(Hkv, D, G, cap) : 4 * stream_shape(G).W;
+    const int n = num_cus() * wpc / Hkv;
     return n < 1 ? 1 : n;
 }
-static inline int stream_rmin(int D, int G) { return 4 * (kWave / (D / 8)) * stream_shape(G).U; }   // >= 4 tiles per range
+static inline int stream_rmin(int D, int G) {                                                       // >= 4 tiles per range
+    return use_mfma() ? mfma_rmin() : 4 * (kWave / (D / 8)) * stream_shape(G).U;
+}
 
 }  // namespace m355
 
 using namespace m355;
 
 extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev-only (not part of include/mi355attn.h)
-    return hipMemcpyToSymbol(HIP_SYMBOL(m355::g_sstamp_buf), &dev_ptr, sizeof(dev_ptr)) == hipSuccess ? 0 : -1;
+    m355::g_stream_stamps = (unsigned long long*)dev_ptr;
+    return 0;
 }
 
 extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
     if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
-    (void)D;
-    return plan_layout(B, stream_nwh(Hkv, G), token_capacity).ints * (int64_t)sizeof(int32_t);
+    return plan_layout(B, stream_nwh(Hkv, D, G, token_capacity), token_capacity).ints * (int64_t)sizeof(int32_t);
 }
 
 extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_table_ids, const int32_t* page_table,
@@ -521,7 +488,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
         return M355_ERR_INVALID_ARG;
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
     if (token_capacity > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
-    const int nwh = stream_nwh(Hkv, G);
+    const int nwh = stream_nwh(Hkv, D, G, token_capacity);
     const PlanLayout L = plan_layout(B, nwh, token_capacity);
     if (plan_bytes < L.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -537,7 +504,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
 extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                                        int64_t token_capacity) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return 0;
-    const PlanLayout L = plan_layout(B, stream_nwh(Hkv, Hq / Hkv), token_capacity);
+    const PlanLayout L = plan_layout(B, stream_nwh(Hkv, D, Hq / Hkv, token_capacity), token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;      // every range boundary and request adds at most one
     return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
 }
@@ -572,7 +539,7 @@ extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, con
         return M355_ERR_INVALID_ARG;
     if ((q_row_stride % 8) || (o_row_stride % 8) || q_row_stride < (int64_t)Hq * D || o_row_stride < (int64_t)Hq * D)
         return M355_ERR_INVALID_ARG;
-    const int nwh = stream_nwh(Hkv, G);
+    const int nwh = stream_nwh(Hkv, D, G, token_capacity);
     const PlanLayout L = plan_layout(B, nwh, token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;
     const int64_t need = n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
@@ -584,7 +551,16 @@ extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, con
     p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = (int64_t)Hkv * D;
     p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_rec = L.rec; p.off_slots = L.slots;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.nwh = nwh; p.max_ranges = L.max_ranges; p.scale_log2 = scale * kLog2e;
+    p.stamps = g_stream_stamps;
+    { static const int rot = [] { const char* e = getenv("M355_STREAM_ROT"); return e ? atoi(e) : 0; }(); p.rot = rot; }
     hipStream_t st = (hipStream_t)stream;
+    if (use_mfma()) {
+        const int rc = launch_stream_mfma(p, D, G, token_capacity, st, getenv("M355_STREAM_STAMP") != nullptr);
+        if (rc != M355_OK) return rc;
+        if (D == 64) hipLaunchKernelGGL((stream_merge_kernel<64>), dim3((unsigned)(B * Hq)), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((stream_merge_kernel<128>), dim3((unsigned)(B * Hq)), dim3(64), 0, st, p);
+        return check_launch();
+    }
 #define M355_CASE(DD, GG) if (D == DD && G == GG) { launch_stream<DD, GG>(p, st); return check_launch(); }
     M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
     M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)

@@ -1,0 +1,58 @@
+// Shared by the planned decode kernels (decode_stream.hip: plan + VALU attention, decode_mfma.hip: MFMA attention).
+#pragma once
+#include "common.h"
+
+namespace m355 {
+
+constexpr int kRMax = 1024;                     // tokens per range (LDS slot staging: 4 KiB)
+constexpr int kMaxPieces = 8;                   // pieces a range record holds (more: the range is walked by scanning cum)
+constexpr int kRec = 4 + 4 * kMaxPieces + 4;    // ints per record: n, np|-1, b0, g0, pieces{b,start,len,pidx}, pad
+constexpr int kSpec = 5;                        // slots loaded per lane together with the record (5*64 = 320 tokens)
+constexpr int kHdrInts = 8;
+
+// plan buffer (int32 words): hdr[8] | cum[B+1] | pbase[B+1] | rec[max_ranges][kRec] | slots[max_ranges][kRMax]
+struct PlanLayout {
+    int64_t cum, pbase, rec, slots, ints;
+    int32_t max_ranges;
+};
+__host__ __device__ inline PlanLayout plan_layout(int32_t B, int32_t nwh, int64_t cap) {
+    PlanLayout L;
+    L.max_ranges = (int32_t)(nwh + cap / kRMax + 2);
+    L.cum = kHdrInts;
+    L.pbase = L.cum + (B + 1);
+    L.rec = (L.pbase + (B + 1) + 3) & ~(int64_t)3;
+    L.slots = L.rec + (int64_t)L.max_ranges * kRec;
+    L.ints = L.slots + (int64_t)L.max_ranges * kRMax;
+    return L;
+}
+
+struct StreamParams {
+    const uint16_t* q;
+    const uint16_t* k_pool;
+    const uint16_t* v_pool;
+    const int32_t* plan;
+    uint16_t* out;
+    float* ws_o;    // [n_partials, Hq, D]
+    float* ws_ml;   // [n_partials, Hq, 2]
+    int64_t q_stride, o_stride, row_elems;
+    int64_t off_cum, off_pbase, off_rec, off_slots;
+    int32_t B, Hq, Hkv, nwh, max_ranges, rot;
+    float scale_log2;
+    unsigned long long* stamps;   // dev-only timing probe (tools/stamp_decode.py), 8 slots per wave; else nullptr
+};
+
+// s_memrealtime per wave at phase boundaries when the STAMP build of a kernel runs with a stamp buffer
+template <bool ON>
+__device__ __forceinline__ void sstamp(const StreamParams& p, int k) {
+    if constexpr (ON)
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
+
+
+
+// MFMA attention kernel (decode_mfma.hip).  Its waves-per-CU is LDS-limited and depends on the token capacity.
+int mfma_waves_per_cu(int Hkv, int D, int G, int64_t cap);
+int mfma_rmin();                 // shortest range (tokens) the plan should make for it
+int launch_stream_mfma(const StreamParams& p, int D, int G, int64_t cap, hipStream_t st, bool stamp);
+
+}  // namespace m355
