@@ -92,7 +92,7 @@ template <int N, int STEP>
 __device__ __forceinline__ void wait_tiles_younger(int younger) {
     // wait until all but `younger` tiles (STEP DMA instructions each) of this wave have landed
     if constexpr (N == 0) { wait_vmcnt<0>(); }
-    else { if (younger >= N) wait_vmcnt<N * STEP>(); else wait_tiles_younger<N - 1, STEP>(younger); }
+    else { if (younger >= N) wait_vmcnt<(N * STEP > 63 ? 63 : N * STEP)>(); else wait_tiles_younger<N - 1, STEP>(younger); }   // vmcnt is 6 bits: a lower bound only waits longer
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? M355_OK : M355_ERR_LAUNCH; }

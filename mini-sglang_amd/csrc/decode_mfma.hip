@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
     const int kg = lane >> 4;                            // 16-lane group = k sub-block
     const int w = blockIdx.x / p.Hkv;
     const int h = blockIdx.x % p.Hkv;
+    if (p.rot >= 100 && h != p.rot - 100) return;        // dev probe: only one kv head streams (M355_STREAM_ROT=100+h)
     const int32_t* plan = p.plan;
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)h * M::ROWB;
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)h * M::ROWB;
@@ -92,15 +93,6 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
     bf16x8 qf[M::KS];
 
     auto run_pass = [&](const int p0, const int np) {
-        // ---- q rows of the pass's pieces -> LDS (ordinary loads: retired before the first counted DMA)
-        for (int i = lane; i < np * G * M::C; i += kWave) {
-            const int k = i / (G * M::C), c = i - k * (G * M::C);
-            *reinterpret_cast<u32x4*>(qsp + i * 16) =
-                *reinterpret_cast<const u32x4*>(p.q + (int64_t)pc[(p0 + k) * 4] * p.q_stride + (int64_t)h * G * D + c * 8);
-        }
-        __syncthreads();
-        wait_vmcnt<0>();
-
         int lk = 0, lit = 0, ck = 0, cit = 0, issued = 0, consumed = 0;
         int l_start = __builtin_amdgcn_readfirstlane(pc[p0 * 4 + 1]);
         int l_len = __builtin_amdgcn_readfirstlane(pc[p0 * 4 + 2]);
@@ -224,11 +216,20 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
             }
         };
 
+        wait_vmcnt<0>();                                 // stores of the previous pass: keep the DMA count exact
         sstamp<STAMP>(p, 2);
         // ---- fill the ring, then: refill the slot consumed last, wait for the oldest stage, consume it
 #pragma unroll
         for (int j = 0; j < R - 1; ++j)
             if (lk < np) issue(j);
+        // ---- q rows of the pass's pieces -> LDS, behind the first stages' DMA (ordinary loads: the compiler's wait
+        // for them also covers the older DMA, which the first consume needs anyway)
+        for (int i = lane; i < np * G * M::C; i += kWave) {
+            const int k = i / (G * M::C), c = i - k * (G * M::C);
+            *reinterpret_cast<u32x4*>(qsp + i * 16) =
+                *reinterpret_cast<const u32x4*>(p.q + (int64_t)pc[(p0 + k) * 4] * p.q_stride + (int64_t)h * G * D + c * 8);
+        }
+        __syncthreads();
         sstamp<STAMP>(p, 3);
         while (ck < np) {
 #pragma unroll
@@ -313,7 +314,7 @@ static int cu_count() {
     return n;
 }
 static int mfma_ring() {
-    static int v = [] { const char* e = getenv("M355_MFMA_RING"); const int x = e ? atoi(e) : 2; return x < 2 ? 2 : (x > 4 ? 4 : x); }();
+    static int v = [] { const char* e = getenv("M355_MFMA_RING"); const int x = e ? atoi(e) : 2; return x < 2 ? 2 : (x > 6 ? 6 : x); }();
     return v;
 }
 static int mfma_max_wpc() {
@@ -350,7 +351,7 @@ static int launch_mfma(const StreamParams& p, int64_t cap, hipStream_t st, bool 
 #define M355_RING(RR) if (R == RR) { \
         if (stamp) hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, true>), grid, block, lds, st, p, slots_cap); \
         else hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, false>), grid, block, lds, st, p, slots_cap); }
-    M355_RING(2) M355_RING(3) M355_RING(4)
+    M355_RING(2) M355_RING(3) M355_RING(4) M355_RING(5) M355_RING(6)
 #undef M355_RING
     return M355_OK;
 }
