@@ -66,8 +66,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
     const int n = lane & 15;                             // q column / K row / d column, by operand
     const int kg = lane >> 4;                            // 16-lane group = k sub-block
     const int w = blockIdx.x / p.Hkv;
-    const int h = blockIdx.x % p.Hkv;
-    if (p.rot >= 100 && h != p.rot - 100) return;        // dev probe: only one kv head streams (M355_STREAM_ROT=100+h)
+    // Workgroups go round-robin over the 8 XCDs, so with h = blockIdx % Hkv one XCD would stream one head only: one
+    // 2*D-byte column of every Hkv*2*D-byte token row, i.e. a fixed value of the low address bits its L2 channels are
+    // interleaved on.  Rotating the head every p.rot ranges lets every XCD touch every column (measured 35.3 -> 31.5 us).
+    const int h = (blockIdx.x + (p.rot > 0 ? w / p.rot : 0)) % p.Hkv;
     const int32_t* plan = p.plan;
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)h * M::ROWB;
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)h * M::ROWB;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
     const int dchunk = lane % LPH;
     const int tsub = lane / LPH;
     const int w = blockIdx.x / p.Hkv;
-    const int h = (blockIdx.x + (p.rot ? w : 0)) % p.Hkv;      // rot: heads rotate over the XCDs from range to range
+    const int h = (blockIdx.x + (p.rot > 0 ? w / p.rot : 0)) % p.Hkv;   // heads rotate over the XCDs every p.rot ranges (see decode_mfma.hip)
     const int32_t* plan = p.plan;
     const int64_t lane_off = (int64_t)h * D + dchunk * 8;
 
@@ -552,7 +552,8 @@ extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, con
     p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_rec = L.rec; p.off_slots = L.slots;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.nwh = nwh; p.max_ranges = L.max_ranges; p.scale_log2 = scale * kLog2e;
     p.stamps = g_stream_stamps;
-    { static const int rot = [] { const char* e = getenv("M355_STREAM_ROT"); return e ? atoi(e) : 0; }(); p.rot = rot; }
+    { static const int rot = [] { const char* e = getenv("M355_STREAM_ROT"); return e ? atoi(e) : 1; }();    // 0: no rotation (A/B)
+      p.rot = rot ? (nwh / Hkv > 0 ? nwh / Hkv : 1) : 0; }
     hipStream_t st = (hipStream_t)stream;
     if (use_mfma()) {
         const int rc = launch_stream_mfma(p, D, G, token_capacity, st, getenv("M355_STREAM_STAMP") != nullptr);

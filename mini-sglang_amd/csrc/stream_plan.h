@@ -36,7 +36,8 @@ struct StreamParams {
     float* ws_ml;   // [n_partials, Hq, 2]
     int64_t q_stride, o_stride, row_elems;
     int64_t off_cum, off_pbase, off_rec, off_slots;
-    int32_t B, Hq, Hkv, nwh, max_ranges, rot;
+    int32_t B, Hq, Hkv, nwh, max_ranges;
+    int32_t rot;                  // kv head of workgroup (w, j) = (j + w / rot) % Hkv; 0 = no rotation
     float scale_log2;
     unsigned long long* stamps;   // dev-only timing probe (tools/stamp_decode.py), 8 slots per wave; else nullptr
 };
