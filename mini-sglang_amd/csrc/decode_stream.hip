@@ -396,20 +396,38 @@ __global__ __launch_bounds__(64) void stream_merge_kernel(const StreamParams p) 
     const int32_t p0 = pbase[b];
     constexpr int E = D / kWave;
     const int lane = threadIdx.x;
-    float mx = kNegBig;
-    for (int s = lane; s < np; s += kWave) mx = fmaxf(mx, p.ws_ml[((int64_t)(p0 + s) * p.Hq + hq) * 2]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    float den = 0.f, acc[E];
+    // All loads of a batch of <= 8 partials go out together (m, l and this lane's slice of o): one memory latency
+    // per batch instead of three dependent ones.
+    float mx = kNegBig, den = 0.f, acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
-    for (int s = 0; s < np; ++s) {
-        const int64_t idx = (int64_t)(p0 + s) * p.Hq + hq;
-        const float wgt = exp2_fast(p.ws_ml[idx * 2] - mx);
-        den += wgt * p.ws_ml[idx * 2 + 1];
-        const float* wo = p.ws_o + idx * D + lane * E;
+    for (int s0 = 0; s0 < np; s0 += 8) {
+        float mm[8], ll[8], oo[8][E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] += wgt * wo[e];
+        for (int j = 0; j < 8; ++j) {
+            const int sj = s0 + j < np ? s0 + j : np - 1;
+            const int64_t idx = (int64_t)(p0 + sj) * p.Hq + hq;
+            mm[j] = p.ws_ml[idx * 2];
+            ll[j] = p.ws_ml[idx * 2 + 1];
+            const float* wo = p.ws_o + idx * D + lane * E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) oo[j][e] = wo[e];
+        }
+        float bm = mx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bm = fmaxf(bm, s0 + j < np ? mm[j] : kNegBig);
+        const float resc = exp2_fast(mx - bm);
+        den *= resc;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] *= resc;
+        mx = bm;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float wgt = s0 + j < np ? exp2_fast(mm[j] - mx) : 0.f;
+            den = fmaf(wgt, ll[j], den);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = fmaf(wgt, oo[j][e], acc[e]);
+        }
     }
     const float inv = 1.f / den;
     uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)hq * D + lane * E;
