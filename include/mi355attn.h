@@ -123,6 +123,19 @@ int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_
                              int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
                              int64_t workspace_bytes, int32_t dtype, void *stream);
 
+/* KV slot write + planned decode attention in ONE launch: the same pool contents and the same output as
+ * m355_kv_store(k_pool, v_pool, k_new, v_new, loc = the step's out_cache_loc) followed by m355_decode_attn_planned,
+ * i.e. one whole TorchNativeAttnBackend.forward_decode (torch_native_backend.py:237-276).  The plan (built after
+ * the step's page-table update) already knows every request's newest slot, so no loc argument is needed: the wave
+ * that owns a request's last token reads that row from k_new / v_new [B, Hkv*D] (row strides in elements) instead
+ * of the pool and writes it to the pool slot.  Saves the ~3.5 us store launch per layer.  Matrix-core kernel only
+ * (M355_ERR_UNSUPPORTED under M355_STREAM_KERNEL=valu). */
+int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const void *k_new, int64_t k_row_stride,
+                                   const void *v_new, int64_t v_row_stride, void *k_pool, void *v_pool,
+                                   const void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                   int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
+                                   int64_t workspace_bytes, int32_t dtype, void *stream);
+
 /* Ragged prefill ("extend") attention over cached prefixes.  Replaces
  * TorchNativeAttnBackend.forward_extend / _run_sdpa_forward_extend
  * (torch_native_backend.py:25-119, 195-235) minus the KV write: packed query row cu_q[b] + j is

@@ -94,11 +94,27 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
     float m_run = kNegBig, l_run = 0.f;
     bf16x8 qf[M::KS];
 
+    const bool fused = p.k_new != nullptr;
+    uint32_t endmask = 0;                                // bit k: piece k of the range ends its request
+
     auto run_pass = [&](const int p0, const int np) {
         int lk = 0, lit = 0, ck = 0, cit = 0, issued = 0, consumed = 0;
         int l_start = __builtin_amdgcn_readfirstlane(pc[p0 * 4 + 1]);
         int l_len = __builtin_amdgcn_readfirstlane(pc[p0 * 4 + 2]);
         int c_len = l_len;
+        // fused KV store: the newest token of a request is read from the step's k/v rows, not from the pool
+        bool l_new = false;
+        const uint8_t* l_knew = nullptr;
+        const uint8_t* l_vnew = nullptr;
+        auto new_rows = [&]() {
+            l_new = fused && ((endmask >> (p0 + lk)) & 1u);
+            if (l_new) {
+                const int64_t bq = __builtin_amdgcn_readfirstlane(pc[(p0 + lk) * 4]);
+                l_knew = reinterpret_cast<const uint8_t*>(p.k_new + bq * p.kn_stride) + h * M::ROWB;
+                l_vnew = reinterpret_cast<const uint8_t*>(p.v_new + bq * p.vn_stride) + h * M::ROWB;
+            }
+        };
+        new_rows();
 
         auto issue = [&](const int RS) {                  // RS: ring slot, a constant after unrolling
             const uint32_t sbase = ring0 + RS * M::STAGEB;
@@ -107,8 +123,9 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                 int tt = lit * 32 + i * M::RPI + drow;
                 tt = tt < l_len ? tt : l_len - 1;         // clamp: rows past the piece are masked in the scores
                 const int64_t ro = (int64_t)slots[l_start + tt] * row_bytes;
-                glds16(kbase + ro + koff[i], sbase + 1024 * i);
-                glds16(vbase + ro + voff[i], sbase + M::TILEB + 1024 * i);
+                const bool fresh = l_new && tt == l_len - 1;
+                glds16((fresh ? l_knew : kbase + ro) + koff[i], sbase + 1024 * i);
+                glds16((fresh ? l_vnew : vbase + ro) + voff[i], sbase + M::TILEB + 1024 * i);
             }
             ++issued;
             ++lit;
@@ -117,6 +134,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                 if (lk < np) {
                     l_start = __builtin_amdgcn_readfirstlane(pc[(p0 + lk) * 4 + 1]);
                     l_len = __builtin_amdgcn_readfirstlane(pc[(p0 + lk) * 4 + 2]);
+                    new_rows();
                 }
             }
         };
@@ -231,6 +249,19 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
             *reinterpret_cast<u32x4*>(qsp + i * 16) =
                 *reinterpret_cast<const u32x4*>(p.q + (int64_t)pc[(p0 + k) * 4] * p.q_stride + (int64_t)h * G * D + c * 8);
         }
+        if (fused) {                                     // ... and the new rows of this head -> their pool slots
+            for (int k = 0; k < np; ++k) {
+                if (!((endmask >> (p0 + k)) & 1u)) continue;
+                if (lane < 2 * M::C) {
+                    const int c = lane % M::C;
+                    const int64_t bq = pc[(p0 + k) * 4];
+                    const int64_t slot = slots[pc[(p0 + k) * 4 + 1] + pc[(p0 + k) * 4 + 2] - 1];
+                    const uint16_t* src = (lane < M::C ? p.k_new + bq * p.kn_stride : p.v_new + bq * p.vn_stride) + h * D + c * 8;
+                    uint16_t* dst = const_cast<uint16_t*>(lane < M::C ? p.k_pool : p.v_pool) + slot * p.row_elems + h * D + c * 8;
+                    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+                }
+            }
+        }
         __syncthreads();
         sstamp<STAMP>(p, 3);
         while (ck < np) {
@@ -276,6 +307,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
         int b_next = __builtin_amdgcn_readfirstlane(rec[2]);
         int32_t done = 0;
         int np = np_rec;
+        endmask = __builtin_amdgcn_readfirstlane(rec[kRecEnds]);
         do {
             if (scanning) {
                 __syncthreads();
@@ -293,6 +325,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                     pc[k * 4 + 2] = hi - lo;
                     pc[k * 4 + 3] = (lo == cs && hi == ce) ? -1 : pbase[bb] + (r - cs / Rt);
                 }
+                const unsigned long long ends = __ballot(have && hi == ce);
+                endmask = 0;
+                for (int j = 0, k = 0; j < kMaxPieces; ++j)
+                    if ((mask >> j) & 1ull) { endmask |= (uint32_t)((ends >> j) & 1ull) << k; ++k; }
                 const int last = 63 - __clzll(mask | 1ull);
                 done = __builtin_amdgcn_readfirstlane((np > 0 ? __shfl(hi, last) : g0 + nt) - g0);
                 b_next = __builtin_amdgcn_readfirstlane(np > 0 ? b_next + last + 1 : b_next + kMaxPieces);

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
         int b = upper_bound_minus1(cum, B, g0);
         rec[0] = g1 - g0; rec[2] = b; rec[3] = g0;
         int np = 0;
+        int32_t endmask = 0;                                 // bit k: piece k ends its request (holds the newest token)
         for (; b < B && cum[b] < g1; ++b) {
             const int32_t cs = cum[b], ce = cum[b + 1];
             const int32_t lo2 = max(cs, g0), hi2 = min(ce, g1);
@@ -101,9 +102,11 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
             rec[4 + np * 4 + 1] = lo2 - g0;
             rec[4 + np * 4 + 2] = hi2 - lo2;
             rec[4 + np * 4 + 3] = (lo2 == cs && hi2 == ce) ? -1 : pbase[b] + (r - cs / R);
+            if (hi2 == ce) endmask |= 1 << np;
             ++np;
         }
         rec[1] = np;
+        rec[kRecEnds] = endmask;
     }
 }
 
@@ -542,10 +545,11 @@ static void launch_stream(const StreamParams& p, hipStream_t st) {
     hipLaunchKernelGGL((stream_merge_kernel<D>), dim3((unsigned)(p.B * p.Hq)), block, 0, st, p);
 }
 
-extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
-                                        const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
-                                        int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
-                                        int64_t workspace_bytes, int32_t dtype, void* stream) {
+static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
+                                    const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                    int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
+                                    int64_t workspace_bytes, int32_t dtype, void* stream, const void* k_new,
+                                    int64_t k_row_stride, const void* v_new, int64_t v_row_stride) {
     if (B == 0) return M355_OK;
     if (!q || !k_pool || !v_pool || !plan || !out || B < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || token_capacity <= 0)
         return M355_ERR_INVALID_ARG;
@@ -565,6 +569,7 @@ extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, con
     StreamParams p;
     p.q = (const uint16_t*)q; p.k_pool = (const uint16_t*)k_pool; p.v_pool = (const uint16_t*)v_pool;
     p.plan = (const int32_t*)plan; p.out = (uint16_t*)out;
+    p.k_new = (const uint16_t*)k_new; p.v_new = (const uint16_t*)v_new; p.kn_stride = k_row_stride; p.vn_stride = v_row_stride;
     p.ws_o = (float*)workspace; p.ws_ml = p.ws_o + n_partials * Hq * D;
     p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = (int64_t)Hkv * D;
     p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_rec = L.rec; p.off_slots = L.slots;
@@ -573,6 +578,7 @@ extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, con
     { static const int rot = [] { const char* e = getenv("M355_STREAM_ROT"); return e ? atoi(e) : 1; }();    // 0: no rotation (A/B)
       p.rot = rot ? (nwh / Hkv > 0 ? nwh / Hkv : 1) : 0; }
     hipStream_t st = (hipStream_t)stream;
+    if (k_new && !use_mfma()) return M355_ERR_UNSUPPORTED;   // the fused store lives in the MFMA kernel only
     if (use_mfma()) {
         const int rc = launch_stream_mfma(p, D, G, token_capacity, st, getenv("M355_STREAM_STAMP") != nullptr);
         if (rc != M355_OK) return rc;
@@ -585,4 +591,26 @@ extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, con
     M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)
 #undef M355_CASE
     return M355_ERR_UNSUPPORTED;
+}
+
+extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
+                                        const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                        int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
+                                        int64_t workspace_bytes, int32_t dtype, void* stream) {
+    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
+                                    token_capacity, workspace, workspace_bytes, dtype, stream, nullptr, 0, nullptr, 0);
+}
+
+extern "C" int m355_decode_store_attn_planned(const void* q, int64_t q_row_stride, const void* k_new, int64_t k_row_stride,
+                                              const void* v_new, int64_t v_row_stride, void* k_pool, void* v_pool,
+                                              const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                              int32_t Hkv, int32_t D, float scale, int64_t token_capacity,
+                                              void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
+    if (B == 0) return M355_OK;
+    if (!k_new || !v_new || k_row_stride < (int64_t)Hkv * D || v_row_stride < (int64_t)Hkv * D || (k_row_stride % 8) ||
+        (v_row_stride % 8) || (((uintptr_t)k_new | (uintptr_t)v_new) & 15))
+        return M355_ERR_INVALID_ARG;
+    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
+                                    token_capacity, workspace, workspace_bytes, dtype, stream, k_new, k_row_stride, v_new,
+                                    v_row_stride);
 }

@@ -7,6 +7,7 @@ namespace m355 {
 constexpr int kRMax = 1024;                     // tokens per range (LDS slot staging: 4 KiB)
 constexpr int kMaxPieces = 8;                   // pieces a range record holds (more: the range is walked by scanning cum)
 constexpr int kRec = 4 + 4 * kMaxPieces + 4;    // ints per record: n, np|-1, b0, g0, pieces{b,start,len,pidx}, pad
+constexpr int kRecEnds = 4 + 4 * kMaxPieces;    // record word: bit k set = piece k ends its request
 constexpr int kSpec = 5;                        // slots loaded per lane together with the record (5*64 = 320 tokens)
 constexpr int kHdrInts = 8;
 
@@ -30,6 +31,9 @@ struct StreamParams {
     const uint16_t* q;
     const uint16_t* k_pool;
     const uint16_t* v_pool;
+    const uint16_t* k_new;        // fused KV store (MFMA kernel): the step's new K/V rows [B, Hkv*D], or nullptr
+    const uint16_t* v_new;
+    int64_t kn_stride, vn_stride;
     const int32_t* plan;
     uint16_t* out;
     float* ws_o;    // [n_partials, Hq, D]

@@ -57,6 +57,9 @@ class MI355AttnBackend:
         self._plan_key = None
         # "planned": per-forward plan + stream-split kernel (default); "chunked": self-contained m355_decode_attn
         self.decode_mode = os.environ.get("M355_DECODE_MODE", "planned")
+        # planned decode on the matrix-core kernel can write the step's K/V rows itself (one launch less per layer)
+        self.fused_store = (os.environ.get("M355_STREAM_KERNEL", "mfma")[:1] != "v"
+                            and os.environ.get("M355_DECODE_FUSED_STORE", "1") != "0")
         self._num_kv_heads_hint = getattr(getattr(model_runner, "kvcache", None), "head_num", None)
 
     # ---- metadata -------------------------------------------------------------------------------
@@ -105,9 +108,12 @@ class MI355AttnBackend:
         if md is None or not md.decode:
             self.init_forward_metadata(batch)
             md = self.forward_metadata
-        self._store_kv(k, v, layer, batch)
         k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
         B = q.shape[0]
+        fuse = (self.decode_mode == "planned" and self.fused_store and k is not None and k.dtype == k_pool.dtype
+                and v.dtype == v_pool.dtype and k.stride(-1) == 1 and v.stride(-1) == 1)
+        if not fuse:
+            self._store_kv(k, v, layer, batch)
         if self.decode_mode == "planned":
             Hq, Hkv, D = layer.num_heads, layer.num_kv_heads, layer.head_dim
             if md.plan is None:                        # first layer of this forward: lay the token stream out once
@@ -116,7 +122,8 @@ class MI355AttnBackend:
                                           self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
                 self._plan_buf = md.plan.buf
             ws = self._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), q.device)
-            return ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws)
+            return ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws,
+                                           k_new=k if fuse else None, v_new=v if fuse else None)
         ws = self._ws(ops.decode_workspace_bytes(B, layer.num_heads, layer.head_dim, md.max_seq_len, md.chunk_tokens),
                       q.device)
         return ops.decode_attn(q.reshape(B, layer.num_heads * layer.head_dim), k_pool, v_pool,

@@ -204,6 +204,39 @@ def test_decode_planned_many_tiny_requests():
     assert torch.allclose(o2.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
 
 
+@pytest.mark.parametrize("Hq,Hkv,D,ps,lens", [
+    (32, 8, 64, 16, [1, 2, 17, 33, 64, 65, 300, 777, 1025, 290, 291]),
+    (32, 8, 128, 16, [5, 130, 2047, 1]),
+    (8, 1, 128, 1, [1, 1, 3, 900]),
+    (8, 2, 64, 4, [int(x) for x in np.random.default_rng(5).integers(1, 6, size=300)]),     # many pieces per range
+])
+def test_decode_fused_store_equals_store_then_attention(Hq, Hkv, D, ps, lens):
+    """m355_decode_store_attn_planned == m355_kv_store + m355_decode_attn_planned: pools bit-exact, output bit-exact
+    (same kernel, the newest row only comes from a different address)."""
+    m, ops = _mods()
+    B = len(lens)
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, lens, seed=B + D)
+    g = torch.Generator().manual_seed(9)
+    qkv = (torch.randn((B, (Hq + 2 * Hkv) * D), generator=g) * 2).to(torch.bfloat16).to(DEV)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)                              # strided views
+    dt, dr, dl = torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV)
+    pos = dl - 1
+    loc = ops.out_cache_loc(dt, dr, pos, ps)
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    kp1, vp1 = kp.to(DEV), vp.to(DEV)
+    ops.kv_store(kp1, vp1, loc, k, v)
+    o1 = ops.decode_attn_planned(q, kp1, vp1, plan, Hq)
+    kp2, vp2 = kp.to(DEV), vp.to(DEV)
+    o2 = ops.decode_attn_planned(q, kp2, vp2, plan, Hq, k_new=k, v_new=v)
+    torch.cuda.synchronize()
+    live = torch.ones(kp1.shape[0], dtype=torch.bool, device=DEV)
+    live[-ps:] = False                                                                      # the NaN poison page
+    assert torch.equal(kp1[live], kp2[live]) and torch.equal(vp1[live], vp2[live])
+    assert torch.equal(o1, o2)
+    ref = _gpu_decode_reference(q.contiguous(), kp1, vp1, dt, rows.tolist(), lens, ps, Hq)
+    assert torch.allclose(o2.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+
+
 def test_decode_planned_more_ranges_than_waves():
     """A token stream longer than waves x 1024 tokens: every wave walks several ranges."""
     m, ops = _mods()
