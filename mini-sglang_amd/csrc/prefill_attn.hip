@@ -226,6 +226,239 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Workgroup-shared variant (default): the 4 waves of a workgroup own 4*RT consecutive row tiles of one
+// (request, kv head) and walk the request's KV together.  Every 32-token K/V tile is brought into LDS ONCE per
+// workgroup with global_load_lds_dwordx4 (whole 2*D-byte rows, XOR-swizzled through the choice of the chunk each
+// lane fetches, double buffered) and consumed by all waves: K fragments are ds_read_b128 rows, V^T fragments
+// ds_read_b64_tr_b16 transposed reads.  L2->CU traffic drops by 4*RT against one-wave-per-tile streaming, which was
+// what bounded the first kernel (3.3 GB per layer on the 8B shared-prefix workload).
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct WgCfg {
+    static constexpr int C = D / 8;                   // 16-byte chunks per row
+    static constexpr int ROWB = 2 * D;
+    static constexpr int RPI = 64 / C;                // rows per DMA instruction
+    static constexpr int NI = 32 / RPI;               // DMA instructions per K (or V) tile
+    static constexpr int IPW = 2 * NI / 4;            // DMA instructions per wave per KV tile (K and V)
+    static constexpr int TILEB = 32 * ROWB;
+    static constexpr int BUFB = 2 * TILEB;            // K tile then V tile
+    static constexpr int KS = D / 16, DT = D / 32;
+    static constexpr int SPAN = 16 / C;               // rows per 256-byte bank span
+    // chunk ch of row `row` sits at position ch ^ s(row): conflict-free 16-row ds_read_b128 column reads of K,
+    // conflict-free 4-row x 64-byte transposed reads of V
+    __device__ static constexpr int sK(int row) { return (row / SPAN) % C; }
+    __device__ static constexpr int sV(int row) { return ((row / SPAN) % (C / 4)) * 4; }
+};
+
+constexpr float kLazy = 8.f;                          // log2 units
+constexpr int kSlotWin = 1024;                        // tokens whose pool slots are staged in LDS at a time
+
+template <int D, int G, int RT, int NBUF, bool POW2>
+__global__ __launch_bounds__(256) void prefill_wg_kernel(const PrefillParams p) {
+    using W = WgCfg<D>;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];     // NBUF x (K tile | V tile), then the slot window
+    int32_t* const slotw = reinterpret_cast<int32_t*>(smem + NBUF * W::BUFB);
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l = threadIdx.x & 63;
+    const int c = l & 31, hh = l >> 5;
+    constexpr int ROWS_WG = 128 * RT;
+
+    int item = blockIdx.x;
+    const int tb = item % p.tiles_max;  item /= p.tiles_max;     // tiles_max: workgroup row blocks per (request, head)
+    const int h = item % p.Hkv;
+    const int b = item / p.Hkv;
+    const int P = (int)p.prefix_lens[b];
+    const int E = (int)p.seq_lens[b] - P;
+    const int rows_b = E * G;
+    if (ROWS_WG * tb >= rows_b) return;                            // whole workgroup: no barrier has been reached yet
+    const int32_t* pt_row = p.page_table + p.page_table_ids[b] * p.pt_stride;
+    const int64_t qrow0 = p.cu_q[b];
+    const int j_last_wg = min(E - 1, (ROWS_WG * tb + ROWS_WG - 1) / G);
+    const int kv_end_wg = P + j_last_wg + 1;                       // tokens any row of the workgroup attends
+    const int n_tiles = (kv_end_wg + 31) >> 5;
+
+    // ---- per row tile: the lane's row, its limit, Q^T fragments
+    int limit[RT], kv_end[RT], kv_min[RT], jrow[RT], grow[RT];
+    bool valid[RT];
+    bf16x8 qf[RT][W::KS];
+    f32x16 o[RT][W::DT];
+    float m_run[RT], l_run[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int t = (tb * 4 + wid) * RT + r;                     // row tile index inside the request
+        const int m = 32 * t + c;
+        valid[r] = m < rows_b;
+        jrow[r] = m / G; grow[r] = m % G;
+        limit[r] = valid[r] ? P + jrow[r] + 1 : 0;
+        kv_end[r] = 32 * t < rows_b ? P + min(E - 1, (32 * t + 31) / G) + 1 : 0;
+        kv_min[r] = P + (32 * t) / G + 1;
+        const uint16_t* qp = p.q + (qrow0 + jrow[r]) * p.q_stride + (int64_t)(h * G + grow[r]) * D + hh * 8;
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (valid[r]) v = *reinterpret_cast<const u32x4*>(qp + s * 16);      // d = 16 s + 8 hh + j: the operand's own order
+            qf[r][s] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int dt = 0; dt < W::DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[r][dt][i] = 0.f;
+        m_run[r] = kNegBig; l_run[r] = 0.f;
+    }
+
+    // ---- DMA duty of this wave: instruction ids wid, wid + 4, ... of the tile's 2*NI (K first, then V)
+    const int drow = l / W::C, dch = l % W::C;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)h * W::ROWB;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)h * W::ROWB;
+    const int64_t row_bytes = p.row_elems * 2;
+    // slots of tokens [win*kSlotWin, +kSlotWin) -> LDS (ordinary loads: the compiler's wait drains the DMA queue too,
+    // once per 32 KV tiles)
+    auto fill_slots = [&](int win) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSlotWin / 256; ++k) {
+            int tok = win * kSlotWin + (int)threadIdx.x + 256 * k;
+            tok = tok < kv_end_wg ? tok : kv_end_wg - 1;
+            const int pg = POW2 ? (tok >> p.ps_shift) : (tok / p.ps);
+            slotw[threadIdx.x + 256 * k] = pt_row[pg] * p.ps + (tok - (POW2 ? (pg << p.ps_shift) : pg * p.ps));
+        }
+        __syncthreads();
+    };
+    auto issue = [&](int tile) {                                   // this wave's share of KV tile `tile`
+        if ((tile & (kSlotWin / 32 - 1)) == 0) fill_slots(tile / (kSlotWin / 32));   // workgroup-uniform
+        const int buf = tile % NBUF;
+#pragma unroll
+        for (int u = 0; u < W::IPW; ++u) {
+            const int id = wid + 4 * u;                            // wave-uniform
+            const bool is_v = id >= W::NI;
+            const int i = id % W::NI;
+            const int row = i * W::RPI + drow;
+            const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
+            const int32_t slot = slotw[((tile * 32) & (kSlotWin - 1)) + row];
+            const uint8_t* src = (is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch;
+            glds16(src, lds0 + buf * W::BUFB + (is_v ? W::TILEB : 0) + 1024 * i);
+        }
+    };
+
+    // ---- LDS read addresses (per lane constants)
+    // K fragment (token row c, k-step s): logical chunk 2 s + hh of row c
+    const int ka0 = c * W::ROWB;
+    const int ksw = W::sK(c);
+    // V^T block: 16-lane group gidx reads 4 token rows x 16 d columns; element order matches the P^T operand
+    const int gidx = l >> 4, li = l & 15;
+    const int vrow = 4 * hh + (li >> 2);
+    const int vcol_chunk = 2 * (gidx & 1) + ((li & 3) >> 1);       // chunk inside the 64-byte d-tile column block
+    const int vsub = 8 * (li & 1);
+
+    wait_vmcnt<0>();                                               // q fragments are in: the DMA count starts clean
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t)
+        if (t < n_tiles) issue(t);
+
+    for (int n = 0; n < n_tiles; ++n) {
+        const int buf = n % NBUF;
+        // this wave's share of tile n has landed when at most the younger tiles' DMA is outstanding
+        wait_tiles_younger<NBUF - 2, W::IPW>(min(NBUF - 2, n_tiles - 1 - n));
+        __syncthreads();                                           // all shares of tile n landed; everyone left tile n-1
+        if (n + NBUF - 1 < n_tiles) issue(n + NBUF - 1);           // into the buffer tile n-1 just vacated
+        const uint8_t* kt = smem + buf * W::BUFB;
+        const uint8_t* vt = kt + W::TILEB;
+        const int base = n * 32;
+        bool any_rt = false;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) any_rt |= base < kv_end[r];
+        if (any_rt) {
+            bf16x8 kf[W::KS];
+#pragma unroll
+            for (int s = 0; s < W::KS; ++s)
+                kf[s] = *reinterpret_cast<const bf16x8*>(kt + ka0 + 16 * ((2 * s + hh) ^ ksw));
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (base >= kv_end[r]) continue;                   // wave-uniform: this row tile is past its diagonal
+                f32x16 s;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < W::KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[r][ks], s, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] *= p.scale_log2;
+                if (base + 32 > kv_min[r]) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int tok = base + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        s[i] = tok < limit[r] ? s[i] : kNegBig;
+                    }
+                }
+                float mx = s[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+                float ma, mb;
+                lane_pair<32>(mx, ma, mb);
+                // lazy running max: move it only when the tile's max beats it by more than 2^kLazy (the rescale of the
+                // O^T accumulators - AGPR round trips - is then rare); p <= 2^kLazy stays well inside bf16 / fp32 range
+                const float m_tile = fmaxf(ma, mb);
+                const float m_new = m_tile > m_run[r] + kLazy ? m_tile : m_run[r];
+                const float alpha = exp2_fast(m_run[r] - m_new);
+                m_run[r] = m_new;
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[i] = exp2_fast(s[i] - m_new); sum += s[i]; }
+                l_run[r] = fmaf(l_run[r], alpha, sum);
+                if (__any(alpha != 1.f)) {
+#pragma unroll
+                    for (int dt = 0; dt < W::DT; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[r][dt][i] *= alpha;
+                }
+                bf16x8 pf[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 w;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) w[x] = pack_bf16(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
+                    pf[ks] = __builtin_bit_cast(bf16x8, w);
+                }
+#pragma unroll
+                for (int dt = 0; dt < W::DT; ++dt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        // rows 16 ks + 4 hh + q (+8): logical chunk 4 dt + vcol_chunk
+                        const int r0 = 16 * ks + vrow;
+                        const uint8_t* a0 = vt + r0 * W::ROWB + 16 * ((4 * dt + vcol_chunk) ^ W::sV(r0)) + vsub;
+                        const uint8_t* a1 = vt + (r0 + 8) * W::ROWB + 16 * ((4 * dt + vcol_chunk) ^ W::sV(r0 + 8)) + vsub;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)a0);
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)a1);
+                        const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[ks], o[r][dt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        float la, lb;
+        lane_pair<32>(l_run[r], la, lb);
+        const float inv = 1.f / (la + lb);
+        if (valid[r]) {
+            uint16_t* op = p.out + (qrow0 + jrow[r]) * p.o_stride + (int64_t)(h * G + grow[r]) * D + 4 * hh;
+#pragma unroll
+            for (int dt = 0; dt < W::DT; ++dt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    uint2 w;
+                    w.x = pack_bf16(o[r][dt][4 * q4 + 0] * inv, o[r][dt][4 * q4 + 1] * inv);
+                    w.y = pack_bf16(o[r][dt][4 * q4 + 2] * inv, o[r][dt][4 * q4 + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + 32 * dt + 8 * q4) = w;
+                }
+        }
+    }
+}
+
 static int ilog2_exact_p(int32_t x) {
     if (x <= 0 || (x & (x - 1))) return -1;
     int s = 0;
@@ -233,9 +466,34 @@ static int ilog2_exact_p(int32_t x) {
     return s;
 }
 
-static int prefill_mode() {      // tuning / cross-check hook: 1 = force the row-parallel (VALU) path
+static int prefill_mode() {      // tuning / cross-check hook: 1 = row-parallel (VALU) path, 2 = one-wave-per-tile MFMA kernel
     static int v = [] { const char* e = getenv("M355_PREFILL_MODE"); return e ? atoi(e) : 0; }();
     return v;
+}
+
+static int prefill_rt() {        // row tiles per wave of the workgroup-shared kernel (1 or 2)
+    static int v = [] { const char* e = getenv("M355_PREFILL_RT"); const int x = e ? atoi(e) : 1; return x == 2 ? 2 : 1; }();
+    return v;
+}
+
+template <int D, int G>
+static void launch_prefill_wg(PrefillParams p, int max_extend_len, hipStream_t st) {
+    const int rt = prefill_rt();
+    p.tiles_max = (max_extend_len * G + 128 * rt - 1) / (128 * rt);
+    const dim3 grid((unsigned)((int64_t)p.B * p.Hkv * p.tiles_max)), block(256);
+    constexpr int NBUF = D == 64 ? 4 : 4;
+    const size_t lds = NBUF * WgCfg<D>::BUFB + kSlotWin * 4;
+    static bool attr_done = [] {
+        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 1, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 1, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 2, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 2, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true; }();
+    (void)attr_done;
+#define M355_WG(RR, PP) hipLaunchKernelGGL((prefill_wg_kernel<D, G, RR, NBUF, PP>), grid, block, lds, st, p)
+    if (rt == 1) { if (p.ps_shift >= 0) M355_WG(1, true); else M355_WG(1, false); }
+    else { if (p.ps_shift >= 0) M355_WG(2, true); else M355_WG(2, false); }
+#undef M355_WG
 }
 
 template <int D, int G>
@@ -290,7 +548,9 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     p.scale_log2 = scale * kLog2e;
     if ((int64_t)B * Hkv * p.tiles_max > 0x7fffffffLL) return M355_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-#define M355_CASE(DD, GG) if (D == DD && G == GG) { launch_prefill<DD, GG>(p, st); return check_launch(); }
+#define M355_CASE(DD, GG) if (D == DD && G == GG) { \
+        if (prefill_mode() == 2) launch_prefill<DD, GG>(p, st); else launch_prefill_wg<DD, GG>(p, max_extend_len, st); \
+        return check_launch(); }
     M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
     M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)
 #undef M355_CASE
