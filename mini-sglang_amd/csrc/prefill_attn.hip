@@ -257,7 +257,7 @@ constexpr int kSlotWin = 1024;                        // tokens whose pool slots
 template <int D, int G, int RT, int NBUF, bool POW2>
 __global__ __launch_bounds__(256) void prefill_wg_kernel(const PrefillParams p) {
     using W = WgCfg<D>;
-    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];     // NBUF x (K tile | V tile), then the slot window
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];     // NBUF K tiles, NBUF V tiles, the slot window
     int32_t* const slotw = reinterpret_cast<int32_t*>(smem + NBUF * W::BUFB);
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int l = threadIdx.x & 63;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void prefill_wg_kernel(const PrefillParams p) 
     constexpr int ROWS_WG = 128 * RT;
 
     int item = blockIdx.x;
-    const int tb = item % p.tiles_max;  item /= p.tiles_max;     // tiles_max: workgroup row blocks per (request, head)
+    const int tb = p.tiles_max - 1 - item % p.tiles_max;  item /= p.tiles_max;   // row block; the longest (latest) first
     const int h = item % p.Hkv;
     const int b = item / p.Hkv;
     const int P = (int)p.prefix_lens[b];
@@ -338,105 +338,121 @@ __global__ __launch_bounds__(256) void prefill_wg_kernel(const PrefillParams p) 
             const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
             const int32_t slot = slotw[((tile * 32) & (kSlotWin - 1)) + row];
             const uint8_t* src = (is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch;
-            glds16(src, lds0 + buf * W::BUFB + (is_v ? W::TILEB : 0) + 1024 * i);
+            glds16(src, lds0 + (is_v ? NBUF * W::TILEB : 0) + buf * W::TILEB + 1024 * i);
         }
     };
 
     // ---- LDS read addresses (per lane constants)
-    // K fragment (token row c, k-step s): logical chunk 2 s + hh of row c
-    const int ka0 = c * W::ROWB;
-    const int ksw = W::sK(c);
-    // V^T block: 16-lane group gidx reads 4 token rows x 16 d columns; element order matches the P^T operand
-    const int gidx = l >> 4, li = l & 15;
-    const int vrow = 4 * hh + (li >> 2);
-    const int vcol_chunk = 2 * (gidx & 1) + ((li & 3) >> 1);       // chunk inside the 64-byte d-tile column block
-    const int vsub = 8 * (li & 1);
+    // K fragment (token row c, k-step s): logical chunk 2 s + hh of row c.  V^T block: 16-lane group gidx reads 4 token
+    // rows x 16 d columns; element order matches the P^T operand.  All per-lane parts are computed once; buffer, k-step
+    // row block and "+8 rows" are immediates of the ds_read instructions (K tiles sit below 32 KiB, V tiles below 64 KiB).
+    uint32_t kaddr[W::KS], vaddr[W::DT];
+    {
+        const int ksw = W::sK(c);
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s) kaddr[s] = lds0 + c * W::ROWB + 16 * ((2 * s + hh) ^ ksw);
+        const int gidx = l >> 4, li = l & 15;
+        const int vrow = 4 * hh + (li >> 2);
+        const int vcol_chunk = 2 * (gidx & 1) + ((li & 3) >> 1);   // chunk inside the 64-byte d-tile column block
+#pragma unroll
+        for (int dt = 0; dt < W::DT; ++dt)
+            vaddr[dt] = lds0 + NBUF * W::TILEB + vrow * W::ROWB + 16 * ((4 * dt + vcol_chunk) ^ W::sV(vrow)) + 8 * (li & 1);
+    }
+    static_assert(2 * NBUF * W::TILEB <= 65536, "ds_read immediates");
 
     wait_vmcnt<0>();                                               // q fragments are in: the DMA count starts clean
 #pragma unroll
     for (int t = 0; t < NBUF - 1; ++t)
         if (t < n_tiles) issue(t);
 
-    for (int n = 0; n < n_tiles; ++n) {
-        const int buf = n % NBUF;
-        // this wave's share of tile n has landed when at most the younger tiles' DMA is outstanding
+    // Per KV tile: wait for this wave's share of the tile, barrier (all shares landed; everyone is past tile n-1),
+    // refill the buffer tile n-1 vacated, then S = K Q^T | softmax | O += V^T P^T.  Overlap of one wave's softmax with
+    // another's MFMAs comes from the 2 waves per SIMD (an in-wave software pipeline was tried: its extra K fragment
+    // registers cost the second wave and it lost: 285 vs 207 us on the 8B workload).
+    auto read_k = [&](bf16x8 (&kf)[W::KS], const int buf) {
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s)
+            kf[s] = *reinterpret_cast<const bf16x8 __attribute__((address_space(3)))*>((uintptr_t)(kaddr[s] + buf * W::TILEB));
+    };
+    auto tile_step = [&](const int n, const int buf) {            // buf == n % NBUF, a constant after unrolling
         wait_tiles_younger<NBUF - 2, W::IPW>(min(NBUF - 2, n_tiles - 1 - n));
-        __syncthreads();                                           // all shares of tile n landed; everyone left tile n-1
-        if (n + NBUF - 1 < n_tiles) issue(n + NBUF - 1);           // into the buffer tile n-1 just vacated
-        const uint8_t* kt = smem + buf * W::BUFB;
-        const uint8_t* vt = kt + W::TILEB;
+        __syncthreads();
+        if (n + NBUF - 1 < n_tiles) issue(n + NBUF - 1);
         const int base = n * 32;
         bool any_rt = false;
 #pragma unroll
         for (int r = 0; r < RT; ++r) any_rt |= base < kv_end[r];
-        if (any_rt) {
-            bf16x8 kf[W::KS];
+        if (!any_rt) return;
+        bf16x8 kf[W::KS];
+        read_k(kf, buf);
+        f32x16 sc[RT];
 #pragma unroll
-            for (int s = 0; s < W::KS; ++s)
-                kf[s] = *reinterpret_cast<const bf16x8*>(kt + ka0 + 16 * ((2 * s + hh) ^ ksw));
+        for (int r = 0; r < RT; ++r) {
 #pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                if (base >= kv_end[r]) continue;                   // wave-uniform: this row tile is past its diagonal
-                f32x16 s;
+            for (int i = 0; i < 16; ++i) sc[r][i] = 0.f;
+            if (base < kv_end[r]) {                                // wave-uniform: not past this row tile's diagonal
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                for (int ks = 0; ks < W::KS; ++ks) sc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[r][ks], sc[r], 0, 0, 0);
+            }
+        }
 #pragma unroll
-                for (int ks = 0; ks < W::KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[r][ks], s, 0, 0, 0);
+        for (int r = 0; r < RT; ++r) {
+            if (base >= kv_end[r]) continue;
+            f32x16& s = sc[r];
+            if (base + 32 > kv_min[r]) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[i] *= p.scale_log2;
-                if (base + 32 > kv_min[r]) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int tok = base + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        s[i] = tok < limit[r] ? s[i] : kNegBig;
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int tok = base + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    s[i] = tok < limit[r] ? s[i] : kNegBig;
                 }
-                float mx = s[0];
+            }
+            float mx = s[0];
 #pragma unroll
-                for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
-                float ma, mb;
-                lane_pair<32>(mx, ma, mb);
-                // lazy running max: move it only when the tile's max beats it by more than 2^kLazy (the rescale of the
-                // O^T accumulators - AGPR round trips - is then rare); p <= 2^kLazy stays well inside bf16 / fp32 range
-                const float m_tile = fmaxf(ma, mb);
-                const float m_new = m_tile > m_run[r] + kLazy ? m_tile : m_run[r];
-                const float alpha = exp2_fast(m_run[r] - m_new);
-                m_run[r] = m_new;
-                float sum = 0.f;
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+            float ma, mb;
+            lane_pair<32>(mx, ma, mb);
+            // lazy running max: move it only when the tile's max beats it by more than 2^kLazy (the rescale of the
+            // O^T accumulators - AGPR round trips - is then rare); p <= 2^kLazy stays well inside bf16 / fp32 range
+            const float m_tile = fmaxf(ma, mb) * p.scale_log2;     // scores stay raw; scale > 0 commutes with max
+            const float m_new = m_tile > m_run[r] + kLazy ? m_tile : m_run[r];
+            const float alpha = exp2_fast(m_run[r] - m_new);
+            m_run[r] = m_new;
+            float sum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { s[i] = exp2_fast(s[i] - m_new); sum += s[i]; }
-                l_run[r] = fmaf(l_run[r], alpha, sum);
-                if (__any(alpha != 1.f)) {
-#pragma unroll
-                    for (int dt = 0; dt < W::DT; ++dt)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) o[r][dt][i] *= alpha;
-                }
-                bf16x8 pf[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    u32x4 w;
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) w[x] = pack_bf16(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
-                    pf[ks] = __builtin_bit_cast(bf16x8, w);
-                }
+            for (int i = 0; i < 16; ++i) { s[i] = exp2_fast(fmaf(s[i], p.scale_log2, -m_new)); sum += s[i]; }
+            l_run[r] = fmaf(l_run[r], alpha, sum);
+            if (__any(alpha != 1.f)) {
 #pragma unroll
                 for (int dt = 0; dt < W::DT; ++dt)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        // rows 16 ks + 4 hh + q (+8): logical chunk 4 dt + vcol_chunk
-                        const int r0 = 16 * ks + vrow;
-                        const uint8_t* a0 = vt + r0 * W::ROWB + 16 * ((4 * dt + vcol_chunk) ^ W::sV(r0)) + vsub;
-                        const uint8_t* a1 = vt + (r0 + 8) * W::ROWB + 16 * ((4 * dt + vcol_chunk) ^ W::sV(r0 + 8)) + vsub;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)a0);
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)a1);
-                        const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[ks], o[r][dt], 0, 0, 0);
-                    }
+                    for (int i = 0; i < 16; ++i) o[r][dt][i] *= alpha;
             }
+            bf16x8 pf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 w;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) w[x] = pack_bf16(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
+                pf[ks] = __builtin_bit_cast(bf16x8, w);
+            }
+#pragma unroll
+            for (int dt = 0; dt < W::DT; ++dt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    // token rows 16 ks + 4 hh + q and + 8 (same swizzle: it only depends on the row modulo 8)
+                    const uint32_t a0 = vaddr[dt] + buf * W::TILEB + 16 * ks * W::ROWB;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + 8 * W::ROWB));
+                    const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[ks], o[r][dt], 0, 0, 0);
+                }
         }
+    };
+    for (int n0 = 0; n0 < n_tiles; n0 += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j)
+            if (n0 + j < n_tiles) tile_step(n0 + j, j);
     }
 
 #pragma unroll
@@ -482,7 +498,7 @@ static void launch_prefill_wg(PrefillParams p, int max_extend_len, hipStream_t s
     p.tiles_max = (max_extend_len * G + 128 * rt - 1) / (128 * rt);
     const dim3 grid((unsigned)((int64_t)p.B * p.Hkv * p.tiles_max)), block(256);
     constexpr int NBUF = D == 64 ? 4 : 4;
-    const size_t lds = NBUF * WgCfg<D>::BUFB + kSlotWin * 4;
+    const size_t lds = NBUF * WgCfg<D>::BUFB + kSlotWin * 4;   // K tiles, V tiles, slot window
     static bool attr_done = [] {
         (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 1, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 1, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
