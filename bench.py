@@ -213,7 +213,8 @@ def main():
                        "heads_per_gpu": [Hq, Hkv, D], "parallelism": f"tp{tp}", "decode_mode": backend.decode_mode,
                        "decode_chunk_tokens": md.chunk_tokens},
             "pct_of_hbm_peak_whole_step": round(100 * value / tp / HBM_PEAK_GBPS, 2),
-            "roofline": {"kernel": "m355::decode_stream_kernel (+ stream_merge_kernel)" if planned
+            "roofline": {"kernel": ("m355::decode_stream_kernel" if os.environ.get("M355_STREAM_KERNEL", "mfma")[:1] == "v"
+                                     else "m355::decode_mfma_kernel") + " (+ stream_merge_kernel)" if planned
                          else "m355::decode_split_kernel (+ decode_merge_kernel)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -235,7 +236,8 @@ def pmc_traffic(planned: bool):
         return None
     with open(files[-1]) as f:
         kernels = json.load(f)["kernels"]
-    want = ("decode_stream_kernel", "stream_merge_kernel") if planned else ("decode_split_kernel", "decode_merge_kernel")
+    main = "decode_stream_kernel" if os.environ.get("M355_STREAM_KERNEL", "mfma")[:1] == "v" else "decode_mfma_kernel"
+    want = (main, "stream_merge_kernel") if planned else ("decode_split_kernel", "decode_merge_kernel")
     tot = 0
     for w in want:
         hit = [e["hbm_bytes_per_launch"] for k, e in kernels.items() if w in k]
