@@ -255,7 +255,7 @@ constexpr float kLazy = 8.f;                          // log2 units
 constexpr int kSlotWin = 1024;                        // tokens whose pool slots are staged in LDS at a time
 
 template <int D, int G, int RT, int NBUF, bool POW2>
-__global__ __launch_bounds__(256) void prefill_wg_kernel(const PrefillParams p) {
+__global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const PrefillParams p) {
     using W = WgCfg<D>;
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];     // NBUF K tiles, NBUF V tiles, the slot window
     int32_t* const slotw = reinterpret_cast<int32_t*>(smem + NBUF * W::BUFB);
@@ -361,98 +361,100 @@ __global__ __launch_bounds__(256) void prefill_wg_kernel(const PrefillParams p) 
     static_assert(2 * NBUF * W::TILEB <= 65536, "ds_read immediates");
 
     wait_vmcnt<0>();                                               // q fragments are in: the DMA count starts clean
-#pragma unroll
-    for (int t = 0; t < NBUF - 1; ++t)
-        if (t < n_tiles) issue(t);
+    static_assert(NBUF == 4, "two pairs of tile buffers");
+    issue(0);
+    if (n_tiles > 1) issue(1);
 
-    // Per KV tile: wait for this wave's share of the tile, barrier (all shares landed; everyone is past tile n-1),
-    // refill the buffer tile n-1 vacated, then S = K Q^T | softmax | O += V^T P^T.  Overlap of one wave's softmax with
-    // another's MFMAs comes from the 2 waves per SIMD (an in-wave software pipeline was tried: its extra K fragment
-    // registers cost the second wave and it lost: 285 vs 207 us on the 8B workload).
+    // KV tiles are consumed in PAIRS so that one wave has two independent chains to interleave: the QK^T MFMAs of
+    // the second tile run under the softmax (VALU) of the first, the PV MFMAs of the first under the softmax of the
+    // second.  Per pair: wait for this wave's DMA, barrier (both tiles landed; everyone left the previous pair),
+    // send the next pair into the buffers the previous pair vacated, compute.  (Keeping a K fragment set alive
+    // across the barrier instead - a deeper software pipeline - cost the second wave per SIMD and lost.)
     auto read_k = [&](bf16x8 (&kf)[W::KS], const int buf) {
 #pragma unroll
         for (int s = 0; s < W::KS; ++s)
             kf[s] = *reinterpret_cast<const bf16x8 __attribute__((address_space(3)))*>((uintptr_t)(kaddr[s] + buf * W::TILEB));
     };
-    auto tile_step = [&](const int n, const int buf) {            // buf == n % NBUF, a constant after unrolling
-        wait_tiles_younger<NBUF - 2, W::IPW>(min(NBUF - 2, n_tiles - 1 - n));
-        __syncthreads();
-        if (n + NBUF - 1 < n_tiles) issue(n + NBUF - 1);
-        const int base = n * 32;
-        bool any_rt = false;
+    auto qk = [&](f32x16& sc, const bf16x8 (&kf)[W::KS], const int r) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) any_rt |= base < kv_end[r];
-        if (!any_rt) return;
-        bf16x8 kf[W::KS];
-        read_k(kf, buf);
-        f32x16 sc[RT];
+        for (int i = 0; i < 16; ++i) sc[i] = 0.f;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
+        for (int ks = 0; ks < W::KS; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[r][ks], sc, 0, 0, 0);
+    };
+    auto softmax = [&](f32x16& s, bf16x8 (&pf)[2], const int r, const int base) {
+        if (base + 32 > kv_min[r]) {                               // wave-uniform: only diagonal tiles pay for the mask
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sc[r][i] = 0.f;
-            if (base < kv_end[r]) {                                // wave-uniform: not past this row tile's diagonal
-#pragma unroll
-                for (int ks = 0; ks < W::KS; ++ks) sc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[r][ks], sc[r], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                const int tok = base + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                s[i] = tok < limit[r] ? s[i] : kNegBig;
             }
         }
+        float mx = s[0];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            if (base >= kv_end[r]) continue;
-            f32x16& s = sc[r];
-            if (base + 32 > kv_min[r]) {
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+        float ma, mb;
+        lane_pair<32>(mx, ma, mb);
+        // lazy running max: move it only when the tile's max beats it by more than 2^kLazy (the rescale of the
+        // O^T accumulators - AGPR round trips - is then rare); p <= 2^kLazy stays well inside bf16 / fp32 range
+        const float m_tile = fmaxf(ma, mb) * p.scale_log2;         // scores stay raw; scale > 0 commutes with max
+        const float m_new = m_tile > m_run[r] + kLazy ? m_tile : m_run[r];
+        const float alpha = exp2_fast(m_run[r] - m_new);
+        m_run[r] = m_new;
+        float sum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int tok = base + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    s[i] = tok < limit[r] ? s[i] : kNegBig;
-                }
-            }
-            float mx = s[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
-            float ma, mb;
-            lane_pair<32>(mx, ma, mb);
-            // lazy running max: move it only when the tile's max beats it by more than 2^kLazy (the rescale of the
-            // O^T accumulators - AGPR round trips - is then rare); p <= 2^kLazy stays well inside bf16 / fp32 range
-            const float m_tile = fmaxf(ma, mb) * p.scale_log2;     // scores stay raw; scale > 0 commutes with max
-            const float m_new = m_tile > m_run[r] + kLazy ? m_tile : m_run[r];
-            const float alpha = exp2_fast(m_run[r] - m_new);
-            m_run[r] = m_new;
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = exp2_fast(fmaf(s[i], p.scale_log2, -m_new)); sum += s[i]; }
-            l_run[r] = fmaf(l_run[r], alpha, sum);
-            if (__any(alpha != 1.f)) {
-#pragma unroll
-                for (int dt = 0; dt < W::DT; ++dt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[r][dt][i] *= alpha;
-            }
-            bf16x8 pf[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 w;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) w[x] = pack_bf16(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
-                pf[ks] = __builtin_bit_cast(bf16x8, w);
-            }
+        for (int i = 0; i < 16; ++i) { s[i] = exp2_fast(fmaf(s[i], p.scale_log2, -m_new)); sum += s[i]; }
+        l_run[r] = fmaf(l_run[r], alpha, sum);
+        if (__any(alpha != 1.f)) {
 #pragma unroll
             for (int dt = 0; dt < W::DT; ++dt)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    // token rows 16 ks + 4 hh + q and + 8 (same swizzle: it only depends on the row modulo 8)
-                    const uint32_t a0 = vaddr[dt] + buf * W::TILEB + 16 * ks * W::ROWB;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a0);
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + 8 * W::ROWB));
-                    const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[ks], o[r][dt], 0, 0, 0);
-                }
+                for (int i = 0; i < 16; ++i) o[r][dt][i] *= alpha;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 w;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) w[x] = pack_bf16(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
+            pf[ks] = __builtin_bit_cast(bf16x8, w);
         }
     };
-    for (int n0 = 0; n0 < n_tiles; n0 += NBUF) {
+    auto pv = [&](const bf16x8 (&pf)[2], const int r, const int buf) {
 #pragma unroll
-        for (int j = 0; j < NBUF; ++j)
-            if (n0 + j < n_tiles) tile_step(n0 + j, j);
+        for (int dt = 0; dt < W::DT; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // token rows 16 ks + 4 hh + q and + 8 (same swizzle: it only depends on the row modulo 8)
+                const uint32_t a0 = vaddr[dt] + buf * W::TILEB + 16 * ks * W::ROWB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + 8 * W::ROWB));
+                const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[ks], o[r][dt], 0, 0, 0);
+            }
+    };
+    auto pair_step = [&](const int k, const int pb) {              // tiles 2k, 2k+1 in buffers 2pb, 2pb+1 (pb static)
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (2 * k + 2 < n_tiles) issue(2 * k + 2);
+        if (2 * k + 3 < n_tiles) issue(2 * k + 3);
+        const int base_a = 64 * k, base_b = 64 * k + 32;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            if (base_a >= kv_end[r]) continue;                     // wave-uniform: past this row tile's diagonal
+            const bool two = 2 * k + 1 < n_tiles && base_b < kv_end[r];
+            bf16x8 kfa[W::KS], kfb[W::KS], pfa[2], pfb[2];
+            f32x16 sa, sb;
+            read_k(kfa, 2 * pb);
+            qk(sa, kfa, r);
+            if (two) { read_k(kfb, 2 * pb + 1); qk(sb, kfb, r); }
+            softmax(sa, pfa, r, base_a);
+            pv(pfa, r, 2 * pb);
+            if (two) { softmax(sb, pfb, r, base_b); pv(pfb, r, 2 * pb + 1); }
+        }
+    };
+    for (int k0 = 0; 2 * k0 < n_tiles; k0 += 2) {
+        pair_step(k0, 0);
+        if (2 * (k0 + 1) < n_tiles) pair_step(k0 + 1, 1);
     }
 
 #pragma unroll
