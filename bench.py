@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=-1, help="decode chunk tokens override (-1: backend heuristic)")
     ap.add_argument("--heads", type=str, default="", help="experiment: Hq,Hkv,D per GPU instead of the 1B shape")
     ap.add_argument("--copies", type=int, default=0, help="experiment: batch = 64 * copies")
+    ap.add_argument("--fixed-len", type=int, default=0, help="experiment: every request has this length (with --batch)")
+    ap.add_argument("--batch", type=int, default=0, help="experiment: batch size for --fixed-len")
+    ap.add_argument("--layers", type=int, default=0, help="experiment: number of layers (distinct KV pools)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,10 +100,14 @@ def main():
         Hq, Hkv, D = (int(x) for x in args.heads.split(","))
     ps = PAGE_SIZE
     lens0 = cfg2_lengths(args.copies or tp)          # global batch 64 * tp
+    if args.fixed_len:
+        lens0 = [args.fixed_len] * (args.batch or 1)
+    if args.layers:
+        L = args.layers
     B = len(lens0)
     total_steps = args.warmup + args.steps + 8
     pages_needed = sum(-(-(l + total_steps) // ps) for l in lens0) + 8
-    ctx = 2048 + 64 + total_steps
+    ctx = max(2048, args.fixed_len) + 64 + total_steps
 
     kv = m.KVCache(size=pages_needed * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16,
                    layer_num=L, device=dev)
@@ -196,7 +203,7 @@ def main():
     bytes_launch = attn_bytes_per_layer(lens_now, Hq, Hkv, D, ps)
     achieved = bytes_launch / (us_per_launch * 1e-6) / 1e9
 
-    traffic = pmc_traffic(planned) if tp == 1 and not args.heads and not args.copies else None
+    traffic = pmc_traffic(planned) if tp == 1 and not (args.heads or args.copies or args.fixed_len or args.layers) else None
 
     cpu = None
     if rank == 0 and tp == 1 and not args.no_cpu_baseline:
