@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void stream_merge_kernel(const StreamParams p) 
 static int num_cus() {
     static int n = [] {
         int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         return v > 0 ? v : 256;
     }();
     return n;

@@ -307,6 +307,51 @@ def test_prefill_attn_ragged_prefix(Hq, Hkv, D, ps):
     np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
 
 
+def _gpu_prefill_reference(q, kp, vp, table, rows, seq, pre, ps, Hq):
+    """torch fp32 on the GPU, one request at a time: row j of the extend sees cached tokens 0 .. pre + j."""
+    Hkv, D = kp.shape[1], kp.shape[2]
+    outs, start = [], 0
+    for b, (L, P) in enumerate(zip(seq, pre)):
+        E = L - P
+        pos = torch.arange(L, device=q.device)
+        slots = table[rows[b], pos // ps].long() * ps + pos % ps
+        k = kp[slots].float().repeat_interleave(Hq // Hkv, dim=1)
+        v = vp[slots].float().repeat_interleave(Hq // Hkv, dim=1)
+        qq = q[start:start + E].view(E, Hq, D).float()
+        s = torch.einsum("ehd,lhd->hel", qq, k) * D ** -0.5
+        mask = pos[None, :] > (P + torch.arange(E, device=q.device))[:, None]
+        s = s.masked_fill(mask[None], float("-inf"))
+        outs.append(torch.einsum("hel,lhd->ehd", torch.softmax(s, dim=-1), v).reshape(E, Hq * D))
+        start += E
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,ps", [(8, 2, 128, 16), (8, 2, 64, 4), (8, 1, 128, 16), (4, 4, 64, 16)])
+def test_prefill_long_sequences_and_late_spike(Hq, Hkv, D, ps):
+    """Several slot windows (> 1024 cached tokens), extends longer than a workgroup's row block, odd tile counts, and
+    one key that dominates late (the lazy running max must still rescale)."""
+    m, ops = _mods()
+    seq = [2500, 2311, 1057, 33]
+    pre = [0, 2096, 1024, 32]
+    pre = [p // ps * ps for p in pre]
+    B = len(seq)
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, seq, seed=3 * D + ps)
+    slot = int(table[rows[0], 2200 // ps]) * ps + 2200 % ps
+    kp[slot] = 1.5                                       # scores of ~ +1.5 * sum(q) tower over N(0, D) for most rows
+    ext = [s - p for s, p in zip(seq, pre)]
+    T = sum(ext)
+    g = torch.Generator().manual_seed(12)
+    q = (torch.randn((T, Hq * D), generator=g) + 0.5).to(torch.bfloat16).to(DEV)
+    dk, dv = kp.to(DEV), vp.to(DEV)
+    dt, dr = torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV)
+    ref = _gpu_prefill_reference(q, dk, dv, dt, rows.tolist(), seq, pre, ps, Hq)
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(ext)]), dtype=torch.int32, device=DEV)
+    o = ops.prefill_attn(q, dk, dv, dt, dr, torch.tensor(seq, device=DEV), torch.tensor(pre, device=DEV), cu, ps, Hq,
+                         max(ext), max(seq))
+    assert torch.isfinite(o.float()).all()
+    assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL), float((o.float() - ref).abs().max())
+
+
 def test_decode_cfg2_full_size_properties():
     """BASELINE.json configs[1] at full size (1B heads, B=64 ragged 146..2046, ps=16, shuffled pages):
     the result must not depend on the chunking, and must match a torch fp32 computation on the GPU."""
