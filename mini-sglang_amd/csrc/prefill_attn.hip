@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const 
             pf[ks] = __builtin_bit_cast(bf16x8, w);
         }
     };
-    auto pv = [&](const bf16x8 (&pf)[2], const int r, const int buf) {
+    // O^T += V^T P^T for every active row tile of the wave: each V^T fragment is read from LDS once and feeds RT MFMAs
+    auto pv = [&](const bf16x8 (&pf)[RT][2], const bool (&act)[RT], const int buf) {
 #pragma unroll
         for (int dt = 0; dt < W::DT; ++dt)
 #pragma unroll
@@ -428,8 +429,10 @@ __global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const 
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a0);
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + 8 * W::ROWB));
-                const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[ks], o[r][dt], 0, 0, 0);
+                const bf16x8 av = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    if (act[r]) o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pf[r][ks], o[r][dt], 0, 0, 0);
             }
     };
     auto pair_step = [&](const int k, const int pb) {              // tiles 2k, 2k+1 in buffers 2pb, 2pb+1 (pb static)
@@ -438,18 +441,35 @@ __global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const 
         if (2 * k + 2 < n_tiles) issue(2 * k + 2);
         if (2 * k + 3 < n_tiles) issue(2 * k + 3);
         const int base_a = 64 * k, base_b = 64 * k + 32;
+        bool act_a[RT], act_b[RT], any_a = false, any_b = false;   // wave-uniform: row tile not past its diagonal
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            if (base_a >= kv_end[r]) continue;                     // wave-uniform: past this row tile's diagonal
-            const bool two = 2 * k + 1 < n_tiles && base_b < kv_end[r];
-            bf16x8 kfa[W::KS], kfb[W::KS], pfa[2], pfb[2];
-            f32x16 sa, sb;
-            read_k(kfa, 2 * pb);
-            qk(sa, kfa, r);
-            if (two) { read_k(kfb, 2 * pb + 1); qk(sb, kfb, r); }
-            softmax(sa, pfa, r, base_a);
-            pv(pfa, r, 2 * pb);
-            if (two) { softmax(sb, pfb, r, base_b); pv(pfb, r, 2 * pb + 1); }
+            act_a[r] = base_a < kv_end[r];
+            act_b[r] = 2 * k + 1 < n_tiles && base_b < kv_end[r];
+            any_a |= act_a[r]; any_b |= act_b[r];
+        }
+        if (!any_a) return;
+        bf16x8 kfa[W::KS], kfb[W::KS], pfa[RT][2], pfb[RT][2];
+        f32x16 sa[RT], sb[RT];
+        read_k(kfa, 2 * pb);                                       // K fragments are read once and shared by the row tiles
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            if (act_a[r]) qk(sa[r], kfa, r);
+        if (any_b) {
+            read_k(kfb, 2 * pb + 1);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                if (act_b[r]) qk(sb[r], kfb, r);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            if (act_a[r]) softmax(sa[r], pfa[r], r, base_a);
+        pv(pfa, act_a, 2 * pb);
+        if (any_b) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                if (act_b[r]) softmax(sb[r], pfb[r], r, base_b);
+            pv(pfb, act_b, 2 * pb + 1);
         }
     };
     for (int k0 = 0; 2 * k0 < n_tiles; k0 += 2) {
