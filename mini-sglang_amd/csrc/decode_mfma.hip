@@ -359,7 +359,10 @@ static int mfma_max_wpc() {
     static int v = [] { const char* e = getenv("M355_MFMA_WPC"); const int x = e ? atoi(e) : 8; return x < 1 ? 1 : (x > 8 ? 8 : x); }();
     return v;
 }
-int mfma_rmin() { return 128; }                          // >= 4 stages per range
+int mfma_rmin() {                                        // shortest range: 4 stages (tuning hook M355_MFMA_RMIN; 64 and 32 measured slower)
+    static int v = [] { const char* e = getenv("M355_MFMA_RMIN"); const int x = e ? atoi(e) : 128; return x < 32 ? 32 : x; }();
+    return v;
+}
 
 // slots a wave stages = the longest range the plan can make for this capacity
 static int mfma_slots_cap(int nwh, int64_t cap) {

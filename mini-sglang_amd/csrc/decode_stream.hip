@@ -386,8 +386,11 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
 }
 
 // One wave per (request, q head): combine the partials of requests cut by range boundaries.
-template <int D>
-__global__ __launch_bounds__(64) void stream_merge_kernel(const StreamParams p) {
+// NW waves per (request, q head): wave v combines partials v, v + NW, ...; the NW results meet in LDS.  NW = 1 for
+// batches whose requests are cut into a few pieces; long contexts in small batches (hundreds of pieces per request)
+// would otherwise walk them in one serial chain of memory latencies.
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void stream_merge_kernel(const StreamParams p) {
     const int b = blockIdx.x / p.Hq;
     const int hq = blockIdx.x % p.Hq;
     const int32_t* pbase = p.plan + p.off_pbase;
@@ -398,17 +401,19 @@ __global__ __launch_bounds__(64) void stream_merge_kernel(const StreamParams p) 
     if (np <= 1) return;                                  // whole request handled by one wave: output already final
     const int32_t p0 = pbase[b];
     constexpr int E = D / kWave;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     // All loads of a batch of <= 8 partials go out together (m, l and this lane's slice of o): one memory latency
     // per batch instead of three dependent ones.
     float mx = kNegBig, den = 0.f, acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
-    for (int s0 = 0; s0 < np; s0 += 8) {
+    const int np_w = (np - wv + NW - 1) / NW;            // partials of this wave: wv, wv + NW, ...
+    for (int s0 = 0; s0 < np_w; s0 += 8) {
         float mm[8], ll[8], oo[8][E];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int sj = s0 + j < np ? s0 + j : np - 1;
+            const int sj = wv + NW * (s0 + j < np_w ? s0 + j : np_w - 1);
             const int64_t idx = (int64_t)(p0 + sj) * p.Hq + hq;
             mm[j] = p.ws_ml[idx * 2];
             ll[j] = p.ws_ml[idx * 2 + 1];
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(64) void stream_merge_kernel(const StreamParams p) 
         }
         float bm = mx;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bm = fmaxf(bm, s0 + j < np ? mm[j] : kNegBig);
+        for (int j = 0; j < 8; ++j) bm = fmaxf(bm, s0 + j < np_w ? mm[j] : kNegBig);
         const float resc = exp2_fast(mx - bm);
         den *= resc;
 #pragma unroll
@@ -426,10 +431,32 @@ __global__ __launch_bounds__(64) void stream_merge_kernel(const StreamParams p) 
         mx = bm;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float wgt = s0 + j < np ? exp2_fast(mm[j] - mx) : 0.f;
+            const float wgt = s0 + j < np_w ? exp2_fast(mm[j] - mx) : 0.f;
             den = fmaf(wgt, ll[j], den);
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = fmaf(wgt, oo[j][e], acc[e]);
+        }
+    }
+    if constexpr (NW > 1) {                              // (mx, den, acc) of the NW waves -> wave 0
+        __shared__ float red[NW][kWave * (E + 2)];
+        red[wv][lane] = mx;                              // mx and den are wave-uniform; every lane writes its copy
+        red[wv][kWave + lane] = den;
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[wv][kWave * (2 + e) + lane] = acc[e];
+        __syncthreads();
+        if (wv != 0) return;
+        float gm = kNegBig;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) gm = fmaxf(gm, red[v][lane]);
+        den = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const float wgt = exp2_fast(red[v][lane] - gm);       // a wave with no partials has mx = -big, den = 0: weight 0
+            den = fmaf(wgt, red[v][kWave + lane], den);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = fmaf(wgt, red[v][kWave * (2 + e) + lane], acc[e]);
         }
     }
     const float inv = 1.f / den;
@@ -530,6 +557,16 @@ extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, in
     return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
 }
 
+// waves per (request, q head) of the merge: about one per 8 expected pieces of a request (ranges per head / requests)
+template <int D>
+static void launch_merge(const StreamParams& p, hipStream_t st) {
+    const int per_req = p.nwh / (p.B > 0 ? p.B : 1);
+    const dim3 grid((unsigned)(p.B * p.Hq));
+    if (per_req >= 64) hipLaunchKernelGGL((stream_merge_kernel<D, 16>), grid, dim3(1024), 0, st, p);
+    else if (per_req >= 16) hipLaunchKernelGGL((stream_merge_kernel<D, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((stream_merge_kernel<D, 1>), grid, dim3(64), 0, st, p);
+}
+
 template <int D, int G>
 static void launch_stream(const StreamParams& p, hipStream_t st) {
     const dim3 grid((unsigned)(p.Hkv * p.nwh)), block(64);
@@ -542,7 +579,7 @@ static void launch_stream(const StreamParams& p, hipStream_t st) {
     else if constexpr (G == 4) { M355_SHAPE(2, 2, 3) M355_SHAPE(2, 4, 2) M355_SHAPE(2, 3, 3) M355_SHAPE(2, 3, 2) }
     else { M355_SHAPE(2, 4, 3) M355_SHAPE(2, 3, 3) }
 #undef M355_SHAPE
-    hipLaunchKernelGGL((stream_merge_kernel<D>), dim3((unsigned)(p.B * p.Hq)), block, 0, st, p);
+    launch_merge<D>(p, st);
 }
 
 static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
@@ -582,8 +619,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     if (use_mfma()) {
         const int rc = launch_stream_mfma(p, D, G, token_capacity, st, getenv("M355_STREAM_STAMP") != nullptr);
         if (rc != M355_OK) return rc;
-        if (D == 64) hipLaunchKernelGGL((stream_merge_kernel<64>), dim3((unsigned)(B * Hq)), dim3(64), 0, st, p);
-        else hipLaunchKernelGGL((stream_merge_kernel<128>), dim3((unsigned)(B * Hq)), dim3(64), 0, st, p);
+        if (D == 64) launch_merge<64>(p, st); else launch_merge<128>(p, st);
         return check_launch();
     }
 #define M355_CASE(DD, GG) if (D == DD && G == GG) { launch_stream<DD, GG>(p, st); return check_launch(); }
