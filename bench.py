@@ -13,8 +13,10 @@ layer, plus the kv_store bytes).  Inputs are resident in HBM before the timed re
 
 N>1 (launched by torch.distributed.run, one rank per GPU): the reference's tensor parallelism - every rank
 owns Hq/N query heads and Hkv/N kv heads of EVERY sequence (models/llama.py:76-87) - with the global batch
-grown to 64*N so per-GPU bytes stay fixed ("weak"), and after each layer's attention the RCCL all-reduce of a
-[B_global, hidden] bf16 tensor that RowParallelLinear issues after o_proj (layers/linear.py:228-232).
+grown to 64*N so per-GPU bytes stay fixed ("weak").  The attention path has no exchange step:
+the timed steps contain no collective.  The one collective of the surrounding layer - the RCCL all-reduce of the
+[B_global, hidden] bf16 o_proj output (layers/linear.py:228-232) - is timed SEPARATELY after the main
+measurement and reported as `allreduce_o_proj`, not folded into `value`.
 
 `roofline`: the decode kernels alone (split + merge launches of m355_decode_attn), HIP-event timed over all
 layers back to back, against 8.0 TB/s.  `cpu_baseline`: the oracle (torch-native algorithm restated in
@@ -141,8 +143,6 @@ def main():
         backend.init_forward_metadata(batch)
         for layer in layers:
             o = layer(q, k, v, batch)
-            if tp > 1:
-                all_reduce_rows(red)                 # the o_proj row-parallel reduction (layers/linear.py:231)
         return o
 
     def fence():
@@ -205,6 +205,25 @@ def main():
 
     traffic = pmc_traffic(planned) if tp == 1 and not (args.heads or args.copies or args.fixed_len or args.layers) else None
 
+    # ---- the layer's one collective, outside the path: o_proj's row-parallel all-reduce, timed on its own
+    allreduce = None
+    if tp > 1:
+        for _ in range(3):
+            all_reduce_rows(red)
+        fence()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(50):
+            all_reduce_rows(red)
+        a1.record()
+        torch.cuda.synchronize()
+        us = torch.tensor([a0.elapsed_time(a1) * 1e3 / 50], device=dev, dtype=torch.float64)
+        dist.all_reduce(us, op=dist.ReduceOp.MAX)
+        nbytes = red.numel() * red.element_size()
+        allreduce = {"tensor": f"[{B}, {hidden}] bf16", "bytes": nbytes, "us": round(float(us.item()), 2),
+                     "algbw_GBps": round(nbytes / float(us.item()) / 1e3, 1),
+                     "busbw_GBps": round(nbytes / float(us.item()) / 1e3 * 2 * (tp - 1) / tp, 1)}
+
     cpu = None
     if rank == 0 and tp == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(kv, pm, batch, q, lens_now, Hq, Hkv, D, ps)
@@ -228,6 +247,8 @@ def main():
                          "us_per_launch": round(us_per_launch, 3), "algorithmic_bytes_per_launch": bytes_launch},
             "cpu_baseline": cpu,
         }
+        if allreduce is not None:
+            line["allreduce_o_proj"] = allreduce
         print(json.dumps(line), flush=True)
     if tp > 1:
         dist.destroy_process_group()
