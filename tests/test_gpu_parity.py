@@ -391,3 +391,13 @@ def test_decode_cfg2_full_size_properties():
         s = torch.einsum("hd,lhd->hl", q[b].view(Hq, D).float(), k) * D ** -0.5
         ref[b] = torch.einsum("hl,lhd->hd", torch.softmax(s, dim=-1), v)
     assert torch.allclose(outs[0], ref.view(B, -1), rtol=BF16_RTOL, atol=BF16_ATOL)
+
+
+def test_random_configurations_sweep():
+    """tools/stress_parity.py for a few seconds: random head shapes, page sizes, batch compositions and prefix
+    splits through planned decode with fused store, chunked decode and prefill, against torch fp32 on the GPU."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py")
+    r = subprocess.run([sys.executable, tool, "1", "6"], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "random configurations passed" in r.stdout
