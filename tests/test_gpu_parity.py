@@ -3,6 +3,8 @@
 Integer / byte results (page tables, positions, out_cache_loc, KV pools) must be bit-exact.  Attention output
 is bf16 and is held to BF16_ATOL/BF16_RTOL of the fp32 reference output stored in the fixtures
 (flow_util.BF16_*: 2e-2 absolute + 2e-2 relative, |v| <= 2 in these inputs)."""
+import os
+import sys
 from types import SimpleNamespace
 
 import numpy as np
