@@ -130,6 +130,18 @@ int main() {
         // head-column: 8 heads x 256 ranges; each (w,h) wave reads column h of pages of range w
         timeit("paged head-column 8x128B per instr, R=16", [&] { read_paged<16, 1><<<256 * 8, 64, 16 * 1024>>>(d, dp, npages / 256, 8, o); });
         timeit("paged head-column 8x128B per instr, R=8", [&] { read_paged<8, 1><<<256 * 8, 64, 8 * 1024>>>(d, dp, npages / 256, 8, o); });
+        // the decode kernel's own size: 2 x 75.8 MB (K and V of one layer) = 9254 pages, 36 per (range, head) wave, cold
+        // (each timed launch reads a different 151 MB window of the 2.4 GB buffer)
+        {
+            const int ppw = 36;
+            int win = 0;
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(e0);
+            for (int i = 0; i < 10; ++i) { read_paged<16, 1><<<256 * 8, 64, 16 * 1024>>>(d, dp + (win % 12) * 256 * ppw, ppw, 8, o); ++win; }
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+            printf("%-44s %7.3f us  %6.2f TB/s\n", "head-column, 151 MB per launch (decode size)", ms * 1e3, 256.0 * ppw * 16384 / (ms * 1e-3) / 1e12);
+        }
         for (int i = 0; i < npages; ++i) hp[i] = i;
         CK(hipMemcpy(dp, hp.data(), npages * sizeof(int), hipMemcpyHostToDevice));
         timeit("head-column, pages in order, R=16", [&] { read_paged<16, 1><<<256 * 8, 64, 16 * 1024>>>(d, dp, npages / 256, 8, o); });
