@@ -26,6 +26,7 @@
 
 namespace m355 {
 
+constexpr float kLazyMax = 8.f;                 // log2 units
 constexpr int kQP = 4;                          // pieces whose q rows are staged in LDS at a time
 constexpr int kLdsPerCU = 160 * 1024;
 
@@ -118,14 +119,28 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
 
         auto issue = [&](const int RS) {                  // RS: ring slot, a constant after unrolling
             const uint32_t sbase = ring0 + RS * M::STAGEB;
+            // all slot look-ups first (one LDS round trip; the DMA asm statements are memory barriers for the compiler)
+            int64_t ro[M::NI];
+            int tt[M::NI];
 #pragma unroll
             for (int i = 0; i < M::NI; ++i) {
-                int tt = lit * 32 + i * M::RPI + drow;
-                tt = tt < l_len ? tt : l_len - 1;         // clamp: rows past the piece are masked in the scores
-                const int64_t ro = (int64_t)slots[l_start + tt] * row_bytes;
-                const bool fresh = l_new && tt == l_len - 1;
-                glds16((fresh ? l_knew : kbase + ro) + koff[i], sbase + 1024 * i);
-                glds16((fresh ? l_vnew : vbase + ro) + voff[i], sbase + M::TILEB + 1024 * i);
+                tt[i] = lit * 32 + i * M::RPI + drow;
+                tt[i] = tt[i] < l_len ? tt[i] : l_len - 1;   // clamp: rows past the piece are masked in the scores
+                ro[i] = (int64_t)slots[l_start + tt[i]] * row_bytes;
+            }
+            if (l_new && (lit + 1) * 32 >= l_len) {       // wave-uniform: this stage holds the request's newest token
+#pragma unroll
+                for (int i = 0; i < M::NI; ++i) {
+                    const bool fresh = tt[i] == l_len - 1;
+                    glds16((fresh ? l_knew : kbase + ro[i]) + koff[i], sbase + 1024 * i);
+                    glds16((fresh ? l_vnew : vbase + ro[i]) + voff[i], sbase + M::TILEB + 1024 * i);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < M::NI; ++i) {
+                    glds16(kbase + ro[i] + koff[i], sbase + 1024 * i);
+                    glds16(vbase + ro[i] + voff[i], sbase + M::TILEB + 1024 * i);
+                }
             }
             ++issued;
             ++lit;
@@ -200,7 +215,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
             mx = fmaxf(a, b);
             lane_pair<32>(mx, a, b);
             mx = fmaxf(a, b);
-            const float m_new = fmaxf(m_run, mx * p.scale_log2);
+            // lazy running max: it moves only when beaten by more than 2^kLazyMax, so rescaling the O^T accumulators is
+            // rare; p <= 2^kLazyMax stays far inside bf16 / fp32 range and the partial (m, l, o) stay consistent
+            const float m_tile = mx * p.scale_log2;
+            const float m_new = m_tile > m_run + kLazyMax ? m_tile : m_run;
             const float alpha = exp2_fast(m_run - m_new);
             m_run = m_new;
             float sum = 0.f;

@@ -88,6 +88,39 @@ __global__ __launch_bounds__(64) void read_paged(const uint8_t* __restrict__ src
     if (smem[threadIdx.x] == 0x77 && ppw == 3) out[0] = 1;
 }
 
+// Stage-wise ring like the decode kernel: groups of GI instructions; wait for the older group, then issue a new one.
+// pages of PB bytes, shuffled; one "pool" or two pools (K and V) interleaved.
+template <int GI, int PB, int POOLS>
+__global__ __launch_bounds__(64) void read_staged(const uint8_t* __restrict__ src, const int* __restrict__ pages, int ppw, size_t pool_stride, uint32_t* out) {
+    extern __shared__ uint8_t smem[];
+    const int lane = threadIdx.x;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    constexpr int IPP = PB / 1024;                        // instructions per page (per pool)
+    const int n = ppw * IPP / (GI / POOLS);               // stages
+    int issued = 0;
+    auto issue_stage = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < GI / POOLS; ++j) {
+            const int q = issued * (GI / POOLS) + j;
+            const int pg = pages[blockIdx.x * ppw + q / IPP];
+            const uint8_t* a = src + (size_t)pg * PB + (q % IPP) * 1024 + lane * 16;
+#pragma unroll
+            for (int pl = 0; pl < POOLS; ++pl) {
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(a + pl * pool_stride), "s"(lds0 + (slot * GI + j * POOLS + pl) * 1024) : "memory");
+            }
+        }
+        ++issued;
+    };
+    issue_stage(0);
+    for (int c = 0; c < n; ++c) {
+        if (issued < n) issue_stage(issued & 1);
+        if (c + 1 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(GI) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (smem[threadIdx.x] == 0x77 && ppw == 3) out[0] = 1;
+}
+
 int main() {
     const size_t bytes = (size_t)2400 << 20;
     uint8_t* d; uint32_t* o;
@@ -107,7 +140,7 @@ int main() {
     timeit("plain dwordx4 U=8  grid 256x8 blocks", [&] { read_plain<8><<<2048, 256>>>((const u32x4*)d, n16, o); });
     timeit("plain dwordx4 U=8  grid 256x16 blocks", [&] { read_plain<8><<<4096, 256>>>((const u32x4*)d, n16, o); });
     timeit("plain dwordx4 U=16 grid 256x4 blocks", [&] { read_plain<16><<<1024, 256>>>((const u32x4*)d, n16, o); });
-    for (int waves : {2048, 4096}) {
+    for (int waves : {1024, 2048, 4096}) {
         const size_t bpw = bytes / waves / 1024 * 1024;
         char nm[96];
         snprintf(nm, sizeof nm, "LDS-DMA R=8  KiB in flight, %d waves", waves);
@@ -141,6 +174,28 @@ int main() {
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
             printf("%-44s %7.3f us  %6.2f TB/s\n", "head-column, 151 MB per launch (decode size)", ms * 1e3, 256.0 * ppw * 16384 / (ms * 1e-3) / 1e12);
+        }
+        {   // staged rings: 1024 waves (4 per CU); 4 KiB pages, one pool / two pools half a buffer apart
+            const int np4 = (int)(bytes / 2 / 4096);      // pages per pool when two pools share the buffer
+            std::vector<int> h4(np4);
+            for (int i = 0; i < np4; ++i) h4[i] = i;
+            for (int i = np4 - 1; i > 0; --i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; int j = (int)(st % (uint64_t)(i + 1)); int t = h4[i]; h4[i] = h4[j]; h4[j] = t; }
+            int* d4; CK(hipMalloc(&d4, np4 * sizeof(int)));
+            CK(hipMemcpy(d4, h4.data(), np4 * sizeof(int), hipMemcpyHostToDevice));
+            const int waves = 1024;
+            auto t2 = [&](const char* name, auto launch, double nbytes) {
+                launch(); (void)hipDeviceSynchronize();
+                (void)hipEventRecord(e0);
+                for (int i = 0; i < 5; ++i) launch();
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+                printf("%-52s %7.3f ms  %6.2f TB/s\n", name, ms, nbytes / (ms * 1e-3) / 1e12);
+            };
+            const int ppw = np4 / waves;
+            t2("staged 16 instr/stage, 4K pages, 2 pools, 1024 waves", [&] { read_staged<16, 4096, 2><<<waves, 64, 32 * 1024>>>(d, d4, ppw, bytes / 2, o); }, 2.0 * waves * ppw * 4096);
+            t2("staged  8 instr/stage, 4K pages, 2 pools, 1024 waves", [&] { read_staged<8, 4096, 2><<<waves, 64, 16 * 1024>>>(d, d4, ppw, bytes / 2, o); }, 2.0 * waves * ppw * 4096);
+            t2("staged 16 instr/stage, 4K pages, 1 pool,  1024 waves", [&] { read_staged<16, 4096, 1><<<waves, 64, 32 * 1024>>>(d, d4, ppw, 0, o); }, 1.0 * waves * ppw * 4096);
+            t2("staged 16 instr/stage, 4K pages, 2 pools, 2048 waves", [&] { read_staged<16, 4096, 2><<<2048, 64, 32 * 1024>>>(d, d4, np4 / 2048, bytes / 2, o); }, 2.0 * 2048 * (np4 / 2048) * 4096);
         }
         for (int i = 0; i < npages; ++i) hp[i] = i;
         CK(hipMemcpy(dp, hp.data(), npages * sizeof(int), hipMemcpyHostToDevice));
