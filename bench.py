@@ -18,8 +18,10 @@ the timed steps contain no collective.  The one collective of the surrounding la
 [B_global, hidden] bf16 o_proj output (layers/linear.py:228-232) - is timed SEPARATELY after the main
 measurement and reported as `allreduce_o_proj`, not folded into `value`.
 
-`roofline`: the decode kernels alone (split + merge launches of m355_decode_attn), HIP-event timed over all
-layers back to back, against 8.0 TB/s.  `cpu_baseline`: the oracle (torch-native algorithm restated in
+`roofline`: the decode launches alone, exactly as the steps make them (decode_mfma_kernel with the fused KV
+store + stream_merge_kernel; M355_BENCH_ROOFLINE_FUSED=0 times the attention-only launch instead), HIP-event
+timed over all layers back to back, against 8.0 TB/s - so the rocprofv3 averages of the same command
+(profiles/rNN_bench_kernel_stats.csv: main + merge) add up to `us_per_launch`.  `cpu_baseline`: the oracle (torch-native algorithm restated in
 oracle/attention_ref.py) on the host cores for one layer of the same batch, rank 0, N=1 only.
 """
 from __future__ import annotations
@@ -171,7 +173,7 @@ def main():
         step_bytes += L * (attn_bytes_per_layer(cur, Hq, Hkv, D, ps) + kv_store_bytes_per_layer(B, Hkv, D))
     value = step_bytes * tp / dt / 1e9               # every rank moves the same number of bytes
 
-    # ---- roofline of the dominant kernel: decode attention launches only, all layers back to back
+    # ---- roofline of the dominant kernel: the steps' decode launches only, all layers back to back
     lens_now = list(batch.seq_lens_host)
     md = backend.forward_metadata
     reps = 20
@@ -180,13 +182,15 @@ def main():
     out = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=dev)
 
     planned = backend.decode_mode == "planned"
+    fused = planned and backend.fused_store and os.environ.get("M355_BENCH_ROOFLINE_FUSED", "1") != "0"   # the launch the steps make
     if planned:
         ws = backend._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), dev)
 
     def attn_only():
         for kp, vp in pools:
             if planned:
-                ops.decode_attn_planned(q, kp, vp, md.plan, Hq, workspace=ws, out=out)
+                ops.decode_attn_planned(q, kp, vp, md.plan, Hq, workspace=ws, out=out, k_new=k if fused else None,
+                                        v_new=v if fused else None)
             else:
                 ops.decode_attn(q, kp, vp, pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, md.max_seq_len,
                                 chunk_tokens=md.chunk_tokens, workspace=ws, out=out)
@@ -200,7 +204,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us_per_launch = e0.elapsed_time(e1) * 1e3 / (reps * L)
-    bytes_launch = attn_bytes_per_layer(lens_now, Hq, Hkv, D, ps)
+    bytes_launch = attn_bytes_per_layer(lens_now, Hq, Hkv, D, ps) + (kv_store_bytes_per_layer(B, Hkv, D) if fused else 0)
     achieved = bytes_launch / (us_per_launch * 1e-6) / 1e9
 
     traffic = pmc_traffic(planned) if tp == 1 and not (args.heads or args.copies or args.fixed_len or args.layers) else None
@@ -244,7 +248,8 @@ def main():
                          else "m355::decode_split_kernel (+ decode_merge_kernel)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "us_per_launch": round(us_per_launch, 3), "algorithmic_bytes_per_launch": bytes_launch},
+                         "us_per_launch": round(us_per_launch, 3), "algorithmic_bytes_per_launch": bytes_launch,
+                         "launch": "attention + fused KV store" if fused else "attention only"},
             "cpu_baseline": cpu,
         }
         if allreduce is not None:
