@@ -30,9 +30,11 @@ __device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
 // f32 -> bf16 round-to-nearest-even through the hardware convert (keeps NaN a NaN)
+// (the two-element vector convert is ONE v_cvt_pk_bf16_f32; two scalar casts cost a convert each plus a shift and an or)
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    __bf16 a = (__bf16)lo, b = (__bf16)hi;
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2v_t));
 }
 
 // x + (x from the lane selected by a GFX9 DPP control); fuses into v_add_f32_dpp
@@ -84,6 +86,43 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// N LDS-DMA loads back to back with ONE save / restore of M0 (each load still needs its own M0 = LDS destination)
+template <int N>
+__device__ __forceinline__ void glds16_batch(const void* const (&src)[N], const uint32_t (&dst)[N]) {
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8, "glds16_batch: unsupported count");
+    uint32_t keep;
+    if constexpr (N == 1) {
+        glds16(src[0], dst[0]);
+    } else if constexpr (N == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst[0]), "s"(dst[1]), "v"(src[0]), "v"(src[1]) : "memory");
+    } else if constexpr (N == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, off\n\t"
+                     "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, off\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst[0]), "s"(dst[1]), "s"(dst[2]), "s"(dst[3]),
+                       "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]) : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, off\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, off\n\t"
+                     "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %11, off\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %12, off\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %13, off\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %14, off\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %15, off\n\t"
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %16, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst[0]), "s"(dst[1]), "s"(dst[2]), "s"(dst[3]), "s"(dst[4]), "s"(dst[5]), "s"(dst[6]), "s"(dst[7]),
+                       "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]) : "memory");
+    }
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }

@@ -37,7 +37,9 @@ struct PrefillParams {
     int64_t q_stride, o_stride, pt_stride, row_elems;
     int32_t B, Hq, Hkv, ps, ps_shift, tiles_max;
     float scale_log2;
+    unsigned long long* stamps;                       // dev-only: per-wave phase cycle sums (STAMP builds)
 };
+static unsigned long long* g_prefill_stamps = nullptr;
 
 template <int D>
 struct PrefillCfg {
@@ -227,11 +229,11 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Workgroup-shared variant (default): the 4 waves of a workgroup own 4*RT consecutive row tiles of one
+// Workgroup-shared variant (default): the 4 waves of a workgroup own 4 consecutive row tiles of one
 // (request, kv head) and walk the request's KV together.  Every 32-token K/V tile is brought into LDS ONCE per
 // workgroup with global_load_lds_dwordx4 (whole 2*D-byte rows, XOR-swizzled through the choice of the chunk each
 // lane fetches, double buffered) and consumed by all waves: K fragments are ds_read_b128 rows, V^T fragments
-// ds_read_b64_tr_b16 transposed reads.  L2->CU traffic drops by 4*RT against one-wave-per-tile streaming, which was
+// ds_read_b64_tr_b16 transposed reads.  L2->CU traffic drops by 4 against one-wave-per-tile streaming, which was
 // what bounded the first kernel (3.3 GB per layer on the 8B shared-prefix workload).
 // ------------------------------------------------------------------------------------------------
 template <int D>
@@ -240,7 +242,6 @@ struct WgCfg {
     static constexpr int ROWB = 2 * D;
     static constexpr int RPI = 64 / C;                // rows per DMA instruction
     static constexpr int NI = 32 / RPI;               // DMA instructions per K (or V) tile
-    static constexpr int IPW = 2 * NI / 4;            // DMA instructions per wave per KV tile (K and V)
     static constexpr int TILEB = 32 * ROWB;
     static constexpr int BUFB = 2 * TILEB;            // K tile then V tile
     static constexpr int KS = D / 16, DT = D / 32;
@@ -251,18 +252,24 @@ struct WgCfg {
     __device__ static constexpr int sV(int row) { return ((row / SPAN) % (C / 4)) * 4; }
 };
 
+template <int V> struct IntC { static constexpr int value = V; };
 constexpr float kLazy = 8.f;                          // log2 units
 constexpr int kSlotWin = 1024;                        // tokens whose pool slots are staged in LDS at a time
 
-template <int D, int G, int RT, int NBUF, bool POW2>
-__global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const PrefillParams p) {
+template <int D, int G, int NW, int NBUF, bool POW2, bool STAMP = false>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(const PrefillParams p) {
     using W = WgCfg<D>;
+    constexpr int NT = 64 * NW;                       // threads
+    constexpr int IPW = 2 * W::NI / NW;               // DMA instructions per wave per KV tile (K and V)
+    constexpr int NP = NBUF / 2;                      // pair slots of the tile ring; NP-1 pairs are in flight ahead
+    static_assert(NBUF % 2 == 0 && NP >= 2 && (2 * W::NI) % NW == 0, "ring geometry");
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];     // NBUF K tiles, NBUF V tiles, the slot window
     int32_t* const slotw = reinterpret_cast<int32_t*>(smem + NBUF * W::BUFB);
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int l = threadIdx.x & 63;
     const int c = l & 31, hh = l >> 5;
-    constexpr int ROWS_WG = 128 * RT;
+    constexpr int ROWS_WG = 32 * NW;
+    static_assert(W::KS == 2 * W::DT, "as many K fragments as V^T fragments per tile: they share registers");
 
     int item = blockIdx.x;
     const int tb = p.tiles_max - 1 - item % p.tiles_max;  item /= p.tiles_max;   // row block; the longest (latest) first
@@ -278,34 +285,30 @@ __global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const 
     const int kv_end_wg = P + j_last_wg + 1;                       // tokens any row of the workgroup attends
     const int n_tiles = (kv_end_wg + 31) >> 5;
 
-    // ---- per row tile: the lane's row, its limit, Q^T fragments
-    int limit[RT], kv_end[RT], kv_min[RT], jrow[RT], grow[RT];
-    bool valid[RT];
-    bf16x8 qf[RT][W::KS];
-    f32x16 o[RT][W::DT];
-    float m_run[RT], l_run[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int t = (tb * 4 + wid) * RT + r;                     // row tile index inside the request
-        const int m = 32 * t + c;
-        valid[r] = m < rows_b;
-        jrow[r] = m / G; grow[r] = m % G;
-        limit[r] = valid[r] ? P + jrow[r] + 1 : 0;
-        kv_end[r] = 32 * t < rows_b ? P + min(E - 1, (32 * t + 31) / G) + 1 : 0;
-        kv_min[r] = P + (32 * t) / G + 1;
-        const uint16_t* qp = p.q + (qrow0 + jrow[r]) * p.q_stride + (int64_t)(h * G + grow[r]) * D + hh * 8;
+    // ---- this wave's row tile: the lane's row, its limit, Q^T fragments
+    const int t = tb * NW + wid;                                   // row tile index inside the request
+    const int mrow = 32 * t + c;
+    const bool valid = mrow < rows_b;
+    const int jrow = mrow / G, grow = mrow % G;
+    const int limit = valid ? P + jrow + 1 : 0;
+    const int kv_end = 32 * t < rows_b ? P + min(E - 1, (32 * t + 31) / G) + 1 : 0;   // wave-uniform
+    const int kv_min = P + (32 * t) / G + 1;
+    bf16x8 qf[W::KS];
+    f32x16 o[W::DT];
+    {
+        const uint16_t* qp = p.q + (qrow0 + jrow) * p.q_stride + (int64_t)(h * G + grow) * D + hh * 8;
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {
             u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (valid[r]) v = *reinterpret_cast<const u32x4*>(qp + s * 16);      // d = 16 s + 8 hh + j: the operand's own order
-            qf[r][s] = __builtin_bit_cast(bf16x8, v);
+            if (valid) v = *reinterpret_cast<const u32x4*>(qp + s * 16);          // d = 16 s + 8 hh + j: the operand's own order
+            qf[s] = __builtin_bit_cast(bf16x8, v);
         }
 #pragma unroll
         for (int dt = 0; dt < W::DT; ++dt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[r][dt][i] = 0.f;
-        m_run[r] = kNegBig; l_run[r] = 0.f;
+            for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
     }
+    float m_run = kNegBig, l_run = 0.f;
 
     // ---- DMA duty of this wave: instruction ids wid, wid + 4, ... of the tile's 2*NI (K first, then V)
     const int drow = l / W::C, dch = l % W::C;
@@ -315,31 +318,43 @@ __global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const 
     const int64_t row_bytes = p.row_elems * 2;
     // slots of tokens [win*kSlotWin, +kSlotWin) -> LDS (ordinary loads: the compiler's wait drains the DMA queue too,
     // once per 32 KV tiles)
+    int cur_win = -1;
     auto fill_slots = [&](int win) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kSlotWin / 256; ++k) {
-            int tok = win * kSlotWin + (int)threadIdx.x + 256 * k;
+        for (int k = 0; k < kSlotWin / NT; ++k) {
+            int tok = win * kSlotWin + (int)threadIdx.x + NT * k;
             tok = tok < kv_end_wg ? tok : kv_end_wg - 1;
             const int pg = POW2 ? (tok >> p.ps_shift) : (tok / p.ps);
-            slotw[threadIdx.x + 256 * k] = pt_row[pg] * p.ps + (tok - (POW2 ? (pg << p.ps_shift) : pg * p.ps));
+            slotw[threadIdx.x + NT * k] = pt_row[pg] * p.ps + (tok - (POW2 ? (pg << p.ps_shift) : pg * p.ps));
         }
         __syncthreads();
+        cur_win = win;
     };
-    auto issue = [&](int tile) {                                   // this wave's share of KV tile `tile`
-        if ((tile & (kSlotWin / 32 - 1)) == 0) fill_slots(tile / (kSlotWin / 32));   // workgroup-uniform
-        const int buf = tile % NBUF;
+    // this wave's share of KV tiles 2*pair, 2*pair+1 into ring buffers buf0, buf0+1: all slot look-ups first, then the
+    // DMA instructions back to back (one at a time each would pay an LDS round trip before its address is known).  A
+    // tile index past the end re-fetches the last tile (finite bytes that the mask then removes), so every pair costs
+    // every wave the same number of DMA instructions.
+    auto issue_pair = [&](const int pair, const int buf0) {
+        if ((2 * pair) / (kSlotWin / 32) != cur_win) fill_slots((2 * pair) / (kSlotWin / 32));   // workgroup-uniform
+        const void* src[2 * IPW];
+        uint32_t dst[2 * IPW];
 #pragma unroll
-        for (int u = 0; u < W::IPW; ++u) {
-            const int id = wid + 4 * u;                            // wave-uniform
-            const bool is_v = id >= W::NI;
-            const int i = id % W::NI;
-            const int row = i * W::RPI + drow;
-            const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
-            const int32_t slot = slotw[((tile * 32) & (kSlotWin - 1)) + row];
-            const uint8_t* src = (is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch;
-            glds16(src, lds0 + (is_v ? NBUF * W::TILEB : 0) + buf * W::TILEB + 1024 * i);
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tile = 2 * pair + tt < n_tiles ? 2 * pair + tt : n_tiles - 1;
+#pragma unroll
+            for (int u = 0; u < IPW; ++u) {
+                const int id = wid + NW * u;                       // wave-uniform
+                const bool is_v = id >= W::NI;
+                const int i = id % W::NI;
+                const int row = i * W::RPI + drow;
+                const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
+                const int32_t slot = slotw[((tile * 32) & (kSlotWin - 1)) + row];
+                src[tt * IPW + u] = (is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch;
+                dst[tt * IPW + u] = lds0 + (is_v ? NBUF * W::TILEB : 0) + (buf0 + tt) * W::TILEB + 1024 * i;
+            }
         }
+        glds16_batch<2 * IPW>(src, dst);
     };
 
     // ---- LDS read addresses (per lane constants)
@@ -358,58 +373,59 @@ __global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const 
         for (int dt = 0; dt < W::DT; ++dt)
             vaddr[dt] = lds0 + NBUF * W::TILEB + vrow * W::ROWB + 16 * ((4 * dt + vcol_chunk) ^ W::sV(vrow)) + 8 * (li & 1);
     }
-    static_assert(2 * NBUF * W::TILEB <= 65536, "ds_read immediates");
+    static_assert(2 * NBUF * W::TILEB <= 131072, "ring fits the LDS");
 
     wait_vmcnt<0>();                                               // q fragments are in: the DMA count starts clean
-    static_assert(NBUF == 4, "two pairs of tile buffers");
-    issue(0);
-    if (n_tiles > 1) issue(1);
+    const int n_pairs = (n_tiles + 1) >> 1;
+#pragma unroll
+    for (int j = 0; j < NP - 1; ++j)
+        if (j < n_pairs) issue_pair(j, 2 * j);
 
-    // KV tiles are consumed in PAIRS so that one wave has two independent chains to interleave: the QK^T MFMAs of
-    // the second tile run under the softmax (VALU) of the first, the PV MFMAs of the first under the softmax of the
-    // second.  Per pair: wait for this wave's DMA, barrier (both tiles landed; everyone left the previous pair),
-    // send the next pair into the buffers the previous pair vacated, compute.  (Keeping a K fragment set alive
-    // across the barrier instead - a deeper software pipeline - cost the second wave per SIMD and lost.)
-    auto read_k = [&](bf16x8 (&kf)[W::KS], const int buf) {
-#pragma unroll
-        for (int s = 0; s < W::KS; ++s)
-            kf[s] = *reinterpret_cast<const bf16x8 __attribute__((address_space(3)))*>((uintptr_t)(kaddr[s] + buf * W::TILEB));
+    // K fragment s of the tile in buffer `buf` (ds_read_b128) and V^T fragment f = 2*dt + ks (two transposed reads:
+    // token rows 16 ks + 4 hh + q and + 8; the swizzle only depends on the row modulo 8)
+    auto rdk = [&](const int buf, const int s) {
+        return *reinterpret_cast<const bf16x8 __attribute__((address_space(3)))*>((uintptr_t)(kaddr[s] + buf * W::TILEB));
     };
-    auto qk = [&](f32x16& sc, const bf16x8 (&kf)[W::KS], const int r) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sc[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < W::KS; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[r][ks], sc, 0, 0, 0);
+    auto rdv = [&](const int buf, const int f) {
+        const uint32_t a0 = vaddr[f >> 1] + buf * W::TILEB + 16 * (f & 1) * W::ROWB;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + 8 * W::ROWB));
+        return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
     };
-    auto softmax = [&](f32x16& s, bf16x8 (&pf)[2], const int r, const int base) {
-        if (base + 32 > kv_min[r]) {                               // wave-uniform: only diagonal tiles pay for the mask
+    auto mask = [&](f32x16& s, const int base) {                   // lane holds tokens base + (i&3) + 8 (i>>2) + 4 hh
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int tok = base + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                s[i] = tok < limit[r] ? s[i] : kNegBig;
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int tok = base + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            s[i] = tok < limit ? s[i] : kNegBig;
         }
+    };
+    auto tile_max = [&](const f32x16& s) {
         float mx = s[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+        return mx;
+    };
+    // lazy running max: it moves only when beaten by more than 2^kLazy, so the rescale of the O^T accumulators is
+    // rare; p <= 2^kLazy stays well inside bf16 / fp32 range.  Returns alpha and rescales O^T when it is not 1.
+    auto new_max = [&](const float mx) {
         float ma, mb;
         lane_pair<32>(mx, ma, mb);
-        // lazy running max: move it only when the tile's max beats it by more than 2^kLazy (the rescale of the
-        // O^T accumulators - AGPR round trips - is then rare); p <= 2^kLazy stays well inside bf16 / fp32 range
         const float m_tile = fmaxf(ma, mb) * p.scale_log2;         // scores stay raw; scale > 0 commutes with max
-        const float m_new = m_tile > m_run[r] + kLazy ? m_tile : m_run[r];
-        const float alpha = exp2_fast(m_run[r] - m_new);
-        m_run[r] = m_new;
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = exp2_fast(fmaf(s[i], p.scale_log2, -m_new)); sum += s[i]; }
-        l_run[r] = fmaf(l_run[r], alpha, sum);
+        const float m_new = m_tile > m_run + kLazy ? m_tile : m_run;
+        const float alpha = exp2_fast(m_run - m_new);
+        m_run = m_new;
         if (__any(alpha != 1.f)) {
 #pragma unroll
             for (int dt = 0; dt < W::DT; ++dt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) o[r][dt][i] *= alpha;
+                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
         }
+        return alpha;
+    };
+    auto exp_pack = [&](f32x16& s, bf16x8 (&pf)[2]) {              // p = 2^(s*scale - m); returns the lane's sum
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = exp2_fast(fmaf(s[i], p.scale_log2, -m_run)); sum += s[i]; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 w;
@@ -417,83 +433,109 @@ __global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void prefill_wg_kernel(const 
             for (int x = 0; x < 4; ++x) w[x] = pack_bf16(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
             pf[ks] = __builtin_bit_cast(bf16x8, w);
         }
+        return sum;
     };
-    // O^T += V^T P^T for every active row tile of the wave: each V^T fragment is read from LDS once and feeds RT MFMAs
-    auto pv = [&](const bf16x8 (&pf)[RT][2], const bool (&act)[RT], const int buf) {
+
+    // KV tiles are consumed in PAIRS (tiles 2k, 2k+1 in buffers 2pb, 2pb+1; pb static).  Per pair: wait for this
+    // wave's DMA, barrier (both tiles landed; everyone left the previous pair), send the next pair into the buffers
+    // the previous pair vacated, then
+    //   all 16 K fragments are requested at once; S_a^T, S_b^T = K Q^T (16 MFMAs; the V^T fragments of tile a are
+    //   read into tile a's K registers behind the second eight, tile b's after them),
+    //   ONE max / rescale decision for the 64 tokens (the only branches), then a straight line of
+    //   exp2 + pack (VALU) and O^T += V^T P^T (16 MFMAs) that the scheduler interleaves.
+    // No MFMA waits on an LDS read it has just issued, and the partner wave on the SIMD finds the matrix pipe free
+    // while this one is in its VALU stretch.
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tfirst = 0;
+    if constexpr (STAMP) { tprev = tfirst = __builtin_amdgcn_s_memtime(); }
+    auto stamp = [&](const int i) {
+        if constexpr (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tacc[i] += t - tprev; tprev = t; }
+    };
+    auto pair_step = [&](const int k, auto pb_const) {
+        constexpr int pb = decltype(pb_const)::value;
+        stamp(5);
+        wait_tiles_younger<NP - 2, 2 * IPW>(n_pairs - 1 - k);      // pair k has landed; up to NP-2 younger pairs stay in flight
+        __syncthreads();
+        stamp(0);
+        if (k + NP - 1 < n_pairs) {                                // into the buffers that pair k-1 vacated
+            constexpr int nb = 2 * ((pb + NP - 1) % NP);
+            issue_pair(k + NP - 1, nb);
+        }
+        stamp(1);
+        const int base_a = 64 * k, base_b = 64 * k + 32;
+        if (base_a >= kv_end) return;                              // wave-uniform: the row tile is past its diagonal
+        bf16x8 fa[W::KS], fb[W::KS], pa[2], pbk[2];
+        f32x16 sa, sb;
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s) fa[s] = rdk(2 * pb, s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s) {                          // S_a^T; tile b's K fragments fill in behind
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], qf[s], sa, 0, 0, 0);
+            fb[s] = rdk(2 * pb + 1, s);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s) {                          // S_b^T; tile a's V^T fragments take tile a's K registers
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], qf[s], sb, 0, 0, 0);
+            fa[s] = rdv(2 * pb, s);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(2);
+        // (a tile b that does not exist - its buffer then holds the last tile again - or lies past this wave's
+        // diagonal is fully masked and adds exactly 0)
+        if (base_b + 32 > kv_min) { mask(sa, base_a); mask(sb, base_b); }         // wave-uniform: only diagonal pairs
+        const float alpha = new_max(fmaxf(tile_max(sa), tile_max(sb)));
+        stamp(3);
+        float sum = exp_pack(sa, pa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s) {                          // O^T += V_a^T P_a^T; tile b's V^T fragments fill in behind
+            o[s >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], pa[s & 1], o[s >> 1], 0, 0, 0);
+            fb[s] = rdv(2 * pb + 1, s);
+        }
+        sum += exp_pack(sb, pbk);                                  // independent of the MFMAs above: interleaved with them
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < W::KS; ++s) o[s >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], pbk[s & 1], o[s >> 1], 0, 0, 0);
+        l_run = fmaf(l_run, alpha, sum);
+        stamp(4);
+    };
+    for (int k0 = 0; k0 < n_pairs; k0 += NP) {
+        pair_step(k0, IntC<0>{});
+        if (k0 + 1 < n_pairs) pair_step(k0 + 1, IntC<1>{});
+        if constexpr (NP > 2) { if (k0 + 2 < n_pairs) pair_step(k0 + 2, IntC<2>{}); }
+        if constexpr (NP > 3) { if (k0 + 3 < n_pairs) pair_step(k0 + 3, IntC<3>{}); }
+        static_assert(NP <= 4, "unrolled pair slots");
+    }
+
+    if constexpr (STAMP) {
+        if (l == 0 && p.stamps) {
+            unsigned long long* d = p.stamps + ((int64_t)blockIdx.x * NW + wid) * 8;
+            for (int i = 0; i < 6; ++i) d[i] = tacc[i];
+            d[6] = __builtin_amdgcn_s_memtime() - tfirst;
+            d[7] = (unsigned long long)n_pairs;
+        }
+    }
+    float la, lb;
+    lane_pair<32>(l_run, la, lb);
+    const float inv = 1.f / (la + lb);
+    if (valid) {
+        uint16_t* op = p.out + (qrow0 + jrow) * p.o_stride + (int64_t)(h * G + grow) * D + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < W::DT; ++dt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // token rows 16 ks + 4 hh + q and + 8 (same swizzle: it only depends on the row modulo 8)
-                const uint32_t a0 = vaddr[dt] + buf * W::TILEB + 16 * ks * W::ROWB;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a0);
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + 8 * W::ROWB));
-                const bf16x8 av = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-#pragma unroll
-                for (int r = 0; r < RT; ++r)
-                    if (act[r]) o[r][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pf[r][ks], o[r][dt], 0, 0, 0);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                uint2 w;
+                w.x = pack_bf16(o[dt][4 * q4 + 0] * inv, o[dt][4 * q4 + 1] * inv);
+                w.y = pack_bf16(o[dt][4 * q4 + 2] * inv, o[dt][4 * q4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * q4) = w;
             }
-    };
-    auto pair_step = [&](const int k, const int pb) {              // tiles 2k, 2k+1 in buffers 2pb, 2pb+1 (pb static)
-        wait_vmcnt<0>();
-        __syncthreads();
-        if (2 * k + 2 < n_tiles) issue(2 * k + 2);
-        if (2 * k + 3 < n_tiles) issue(2 * k + 3);
-        const int base_a = 64 * k, base_b = 64 * k + 32;
-        bool act_a[RT], act_b[RT], any_a = false, any_b = false;   // wave-uniform: row tile not past its diagonal
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            act_a[r] = base_a < kv_end[r];
-            act_b[r] = 2 * k + 1 < n_tiles && base_b < kv_end[r];
-            any_a |= act_a[r]; any_b |= act_b[r];
-        }
-        if (!any_a) return;
-        bf16x8 kfa[W::KS], kfb[W::KS], pfa[RT][2], pfb[RT][2];
-        f32x16 sa[RT], sb[RT];
-        read_k(kfa, 2 * pb);                                       // K fragments are read once and shared by the row tiles
-#pragma unroll
-        for (int r = 0; r < RT; ++r)
-            if (act_a[r]) qk(sa[r], kfa, r);
-        if (any_b) {
-            read_k(kfb, 2 * pb + 1);
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-                if (act_b[r]) qk(sb[r], kfb, r);
-        }
-#pragma unroll
-        for (int r = 0; r < RT; ++r)
-            if (act_a[r]) softmax(sa[r], pfa[r], r, base_a);
-        pv(pfa, act_a, 2 * pb);
-        if (any_b) {
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-                if (act_b[r]) softmax(sb[r], pfb[r], r, base_b);
-            pv(pfb, act_b, 2 * pb + 1);
-        }
-    };
-    for (int k0 = 0; 2 * k0 < n_tiles; k0 += 2) {
-        pair_step(k0, 0);
-        if (2 * (k0 + 1) < n_tiles) pair_step(k0 + 1, 1);
-    }
-
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        float la, lb;
-        lane_pair<32>(l_run[r], la, lb);
-        const float inv = 1.f / (la + lb);
-        if (valid[r]) {
-            uint16_t* op = p.out + (qrow0 + jrow[r]) * p.o_stride + (int64_t)(h * G + grow[r]) * D + 4 * hh;
-#pragma unroll
-            for (int dt = 0; dt < W::DT; ++dt)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    uint2 w;
-                    w.x = pack_bf16(o[r][dt][4 * q4 + 0] * inv, o[r][dt][4 * q4 + 1] * inv);
-                    w.y = pack_bf16(o[r][dt][4 * q4 + 2] * inv, o[r][dt][4 * q4 + 3] * inv);
-                    *reinterpret_cast<uint2*>(op + 32 * dt + 8 * q4) = w;
-                }
-        }
     }
 }
 
@@ -509,29 +551,44 @@ static int prefill_mode() {      // tuning / cross-check hook: 1 = row-parallel 
     return v;
 }
 
-static int prefill_rt() {        // row tiles per wave of the workgroup-shared kernel (1 or 2)
-    static int v = [] { const char* e = getenv("M355_PREFILL_RT"); const int x = e ? atoi(e) : 1; return x == 2 ? 2 : 1; }();
+static int prefill_wg_cfg() {    // tuning hook: M355_PREFILL_WG = 10*waves + ring tiles/4, e.g. 41 (4 waves, 4 tiles), 42, 82
+    static int v = [] { const char* e = getenv("M355_PREFILL_WG"); return e ? atoi(e) : 0; }();
     return v;
 }
 
-template <int D, int G>
-static void launch_prefill_wg(PrefillParams p, int max_extend_len, hipStream_t st) {
-    const int rt = prefill_rt();
-    p.tiles_max = (max_extend_len * G + 128 * rt - 1) / (128 * rt);
-    const dim3 grid((unsigned)((int64_t)p.B * p.Hkv * p.tiles_max)), block(256);
-    constexpr int NBUF = D == 64 ? 4 : 4;
+template <int D, int G, int NW, int NBUF>
+static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream_t st) {
+    p.tiles_max = (max_extend_len * G + 32 * NW - 1) / (32 * NW);
+    const dim3 grid((unsigned)((int64_t)p.B * p.Hkv * p.tiles_max)), block(64 * NW);
     const size_t lds = NBUF * WgCfg<D>::BUFB + kSlotWin * 4;   // K tiles, V tiles, slot window
     static bool attr_done = [] {
-        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 1, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 1, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 2, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 2, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, NW, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, NW, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true; }();
     (void)attr_done;
-#define M355_WG(RR, PP) hipLaunchKernelGGL((prefill_wg_kernel<D, G, RR, NBUF, PP>), grid, block, lds, st, p)
-    if (rt == 1) { if (p.ps_shift >= 0) M355_WG(1, true); else M355_WG(1, false); }
-    else { if (p.ps_shift >= 0) M355_WG(2, true); else M355_WG(2, false); }
-#undef M355_WG
+    if constexpr (D == 128 && G == 4) {                            // dev-only phase stamps (tools/stamp_prefill.py)
+        if (g_prefill_stamps && p.ps_shift >= 0) {
+            p.stamps = g_prefill_stamps;
+            (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, NW, NBUF, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((prefill_wg_kernel<D, G, NW, NBUF, true, true>), grid, block, lds, st, p);
+            return;
+        }
+    }
+    if (p.ps_shift >= 0) hipLaunchKernelGGL((prefill_wg_kernel<D, G, NW, NBUF, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((prefill_wg_kernel<D, G, NW, NBUF, false>), grid, block, lds, st, p);
+}
+
+template <int D, int G>
+static void launch_prefill_wg(const PrefillParams& p, int max_extend_len, hipStream_t st) {
+    const int cfg = prefill_wg_cfg();
+    if constexpr (D == 64) {
+        if (cfg == 41) return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
+        if (cfg == 82) return launch_prefill_wg_cfg<D, G, 8, 8>(p, max_extend_len, st);
+        return launch_prefill_wg_cfg<D, G, 4, 8>(p, max_extend_len, st);
+    } else {
+        if (cfg == 82) return launch_prefill_wg_cfg<D, G, 8, 8>(p, max_extend_len, st);
+        return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
+    }
 }
 
 template <int D, int G>
@@ -546,6 +603,11 @@ static void launch_prefill(const PrefillParams& p, hipStream_t st) {
 }  // namespace m355
 
 using namespace m355;
+
+extern "C" int m355dbg_set_prefill_stamp_buffer(void* dev_ptr) {   // dev-only (not part of include/mi355attn.h)
+    m355::g_prefill_stamps = (unsigned long long*)dev_ptr;
+    return 0;
+}
 
 extern "C" int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D, int32_t max_seq_len_hint) {
     if (T <= 0 || Hq <= 0 || D <= 0 || max_seq_len_hint <= 0) return 0;
@@ -584,6 +646,7 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.ps = page_size; p.ps_shift = ilog2_exact_p(page_size);
     p.tiles_max = (max_extend_len * G + 31) / 32;
     p.scale_log2 = scale * kLog2e;
+    p.stamps = nullptr;
     if ((int64_t)B * Hkv * p.tiles_max > 0x7fffffffLL) return M355_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define M355_CASE(DD, GG) if (D == DD && G == GG) { \
