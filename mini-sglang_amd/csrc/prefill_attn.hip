@@ -271,10 +271,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     constexpr int ROWS_WG = 32 * NW;
     static_assert(W::KS == 2 * W::DT, "as many K fragments as V^T fragments per tile: they share registers");
 
-    int item = blockIdx.x;
-    const int tb = p.tiles_max - 1 - item % p.tiles_max;  item /= p.tiles_max;   // row block; the longest (latest) first
-    const int h = item % p.Hkv;
-    const int b = item / p.Hkv;
+    // XCD-aware order: workgroups go round-robin over the 8 XCDs, so blockIdx % 8 names an XCD.  All row blocks of one
+    // (request, kv head) - which stream the same K/V - are given to ONE XCD, next to each other in its dispatch
+    // order and longest (latest) first, so that its L2 fetches that K/V once instead of all eight L2s fetching it
+    // (L2 hit rate 64 % -> 90 % on the shared-prefix workload).  Pairs left over after the last full round of 8 are
+    // spread over all XCDs as before (one pair on one XCD would leave seven idle).
+    const int n_bh = p.B * p.Hkv;
+    const int mapped = (n_bh >> 3) * 8 * p.tiles_max;              // workgroups of the full rounds
+    int tb, bh;
+    if ((int)blockIdx.x < mapped) {
+        int item = blockIdx.x >> 3;
+        tb = p.tiles_max - 1 - item % p.tiles_max;
+        bh = (item / p.tiles_max) * 8 + (blockIdx.x & 7);
+    } else {
+        const int item = blockIdx.x - mapped;
+        tb = p.tiles_max - 1 - item % p.tiles_max;
+        bh = (n_bh & ~7) + item / p.tiles_max;
+    }
+    const int h = bh % p.Hkv;
+    const int b = bh / p.Hkv;
     const int P = (int)p.prefix_lens[b];
     const int E = (int)p.seq_lens[b] - P;
     const int rows_b = E * G;
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     const int j_last_wg = min(E - 1, (ROWS_WG * tb + ROWS_WG - 1) / G);
     const int kv_end_wg = P + j_last_wg + 1;                       // tokens any row of the workgroup attends
     const int n_tiles = (kv_end_wg + 31) >> 5;
+    const int n_pairs = (n_tiles + 1) >> 1;
 
     // ---- this wave's row tile: the lane's row, its limit, Q^T fragments
     const int t = tb * NW + wid;                                   // row tile index inside the request
@@ -331,30 +347,34 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         __syncthreads();
         cur_win = win;
     };
-    // this wave's share of KV tiles 2*pair, 2*pair+1 into ring buffers buf0, buf0+1: all slot look-ups first, then the
-    // DMA instructions back to back (one at a time each would pay an LDS round trip before its address is known).  A
-    // tile index past the end re-fetches the last tile (finite bytes that the mask then removes), so every pair costs
-    // every wave the same number of DMA instructions.
-    auto issue_pair = [&](const int pair, const int buf0) {
+    // This wave's share of KV tiles 2*pair, 2*pair+1 (ring buffers buf0, buf0+1): IPW K pieces and IPW V pieces of
+    // 1 KiB, K and V of the same token rows, so one slot look-up serves a K piece and a V piece.  A pair or tile index
+    // past the end re-fetches the last one (finite bytes that the mask removes, into a vacated buffer), so every
+    // pair costs every wave the same number of DMA instructions and the vmcnt arithmetic is static.
+    // Piece x (0..IPW-1): tile x / (IPW/2) of the pair, DMA row block i = wid + NW * (x % (IPW/2)).
+    static_assert(IPW % 2 == 0 && W::NI % NW == 0, "a wave's K pieces and V pieces cover the same rows");
+    constexpr int HP = IPW / 2;
+    auto pair_slots = [&](int pair, int32_t (&sl)[IPW]) {
+        pair = pair < n_pairs ? pair : n_pairs - 1;
         if ((2 * pair) / (kSlotWin / 32) != cur_win) fill_slots((2 * pair) / (kSlotWin / 32));   // workgroup-uniform
-        const void* src[2 * IPW];
-        uint32_t dst[2 * IPW];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int tile = 2 * pair + tt < n_tiles ? 2 * pair + tt : n_tiles - 1;
-#pragma unroll
-            for (int u = 0; u < IPW; ++u) {
-                const int id = wid + NW * u;                       // wave-uniform
-                const bool is_v = id >= W::NI;
-                const int i = id % W::NI;
-                const int row = i * W::RPI + drow;
-                const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
-                const int32_t slot = slotw[((tile * 32) & (kSlotWin - 1)) + row];
-                src[tt * IPW + u] = (is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch;
-                dst[tt * IPW + u] = lds0 + (is_v ? NBUF * W::TILEB : 0) + (buf0 + tt) * W::TILEB + 1024 * i;
-            }
+        for (int x = 0; x < IPW; ++x) {
+            const int tile = 2 * pair + x / HP < n_tiles ? 2 * pair + x / HP : n_tiles - 1;
+            sl[x] = slotw[((tile * 32) & (kSlotWin - 1)) + (wid + NW * (x % HP)) * W::RPI + drow];
         }
-        glds16_batch<2 * IPW>(src, dst);
+    };
+    auto piece = [&](const bool is_v, const int x, const int32_t slot, const int buf0) {
+        const int i = wid + NW * (x % HP);                         // wave-uniform
+        const int row = i * W::RPI + drow;
+        const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
+        glds16((is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch,
+               lds0 + (is_v ? NBUF * W::TILEB : 0) + (buf0 + x / HP) * W::TILEB + 1024 * i);
+    };
+    auto issue_pair = [&](const int pair, const int buf0) {         // prologue: everything at once
+        int32_t sl[IPW];
+        pair_slots(pair, sl);
+#pragma unroll
+        for (int x = 0; x < IPW; ++x) { piece(false, x, sl[x], buf0); piece(true, x, sl[x], buf0); }
     };
 
     // ---- LDS read addresses (per lane constants)
@@ -376,10 +396,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     static_assert(2 * NBUF * W::TILEB <= 131072, "ring fits the LDS");
 
     wait_vmcnt<0>();                                               // q fragments are in: the DMA count starts clean
-    const int n_pairs = (n_tiles + 1) >> 1;
 #pragma unroll
     for (int j = 0; j < NP - 1; ++j)
-        if (j < n_pairs) issue_pair(j, 2 * j);
+        issue_pair(j, 2 * j);
 
     // K fragment s of the tile in buffer `buf` (ds_read_b128) and V^T fragment f = 2*dt + ks (two transposed reads:
     // token rows 16 ks + 4 hh + q and + 8; the swizzle only depends on the row modulo 8)
@@ -445,24 +464,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     //   exp2 + pack (VALU) and O^T += V^T P^T (16 MFMAs) that the scheduler interleaves.
     // No MFMA waits on an LDS read it has just issued, and the partner wave on the SIMD finds the matrix pipe free
     // while this one is in its VALU stretch.
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tfirst = 0;
-    if constexpr (STAMP) { tprev = tfirst = __builtin_amdgcn_s_memtime(); }
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tfirst = 0, rfirst = 0;
+    if constexpr (STAMP) { tprev = tfirst = __builtin_amdgcn_s_memtime(); rfirst = __builtin_amdgcn_s_memrealtime(); }
     auto stamp = [&](const int i) {
         if constexpr (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tacc[i] += t - tprev; tprev = t; }
     };
     auto pair_step = [&](const int k, auto pb_const) {
         constexpr int pb = decltype(pb_const)::value;
-        stamp(5);
-        wait_tiles_younger<NP - 2, 2 * IPW>(n_pairs - 1 - k);      // pair k has landed; up to NP-2 younger pairs stay in flight
+        stamp(4);
+        wait_vmcnt<(NP - 2) * 2 * IPW>();                          // pair k has landed; NP-2 younger pairs stay in flight
         __syncthreads();
         stamp(0);
-        if (k + NP - 1 < n_pairs) {                                // into the buffers that pair k-1 vacated
-            constexpr int nb = 2 * ((pb + NP - 1) % NP);
-            issue_pair(k + NP - 1, nb);
-        }
+        // the pair NP-1 ahead goes into the buffers that pair k-1 vacated (slots now, DMA further down)
+        constexpr int nb = 2 * ((pb + NP - 1) % NP);
+        int32_t sl[IPW];
+        pair_slots(k + NP - 1, sl);
         stamp(1);
         const int base_a = 64 * k, base_b = 64 * k + 32;
-        if (base_a >= kv_end) return;                              // wave-uniform: the row tile is past its diagonal
+        if (base_a >= kv_end) {                                    // wave-uniform: the row tile is past its diagonal
+#pragma unroll
+            for (int x = 0; x < IPW; ++x) { piece(false, x, sl[x], nb); piece(true, x, sl[x], nb); }
+            return;
+        }
         bf16x8 fa[W::KS], fb[W::KS], pa[2], pbk[2];
         f32x16 sa, sb;
 #pragma unroll
@@ -482,16 +505,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         for (int s = 0; s < W::KS; ++s) {                          // S_b^T; tile a's V^T fragments take tile a's K registers
             sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], qf[s], sb, 0, 0, 0);
             fa[s] = rdv(2 * pb, s);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         stamp(2);
+        // the next pair's DMA goes out in the VALU-only stretches (beside LDS reads and MFMA issue a piece costs the
+        // wave several times more): K pieces before the max, V pieces before the exponentials
+#pragma unroll
+        for (int x = 0; x < IPW; ++x) piece(false, x, sl[x], nb);
         // (a tile b that does not exist - its buffer then holds the last tile again - or lies past this wave's
         // diagonal is fully masked and adds exactly 0)
         if (base_b + 32 > kv_min) { mask(sa, base_a); mask(sb, base_b); }         // wave-uniform: only diagonal pairs
         const float alpha = new_max(fmaxf(tile_max(sa), tile_max(sb)));
         stamp(3);
+#pragma unroll
+        for (int x = 0; x < IPW; ++x) piece(true, x, sl[x], nb);
         float sum = exp_pack(sa, pa);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -514,10 +541,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         static_assert(NP <= 4, "unrolled pair slots");
     }
 
+    wait_vmcnt<0>();                                               // the clamped re-fetches of the last pairs must not outlive the wave
     if constexpr (STAMP) {
         if (l == 0 && p.stamps) {
             unsigned long long* d = p.stamps + ((int64_t)blockIdx.x * NW + wid) * 8;
-            for (int i = 0; i < 6; ++i) d[i] = tacc[i];
+            for (int i = 0; i < 5; ++i) d[i] = tacc[i];
+            d[5] = __builtin_amdgcn_s_memrealtime() - rfirst;      // 100 MHz ticks (the 'between pairs' sum is folded into phase 4)
             d[6] = __builtin_amdgcn_s_memtime() - tfirst;
             d[7] = (unsigned long long)n_pairs;
         }
@@ -582,9 +611,8 @@ template <int D, int G>
 static void launch_prefill_wg(const PrefillParams& p, int max_extend_len, hipStream_t st) {
     const int cfg = prefill_wg_cfg();
     if constexpr (D == 64) {
-        if (cfg == 41) return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
-        if (cfg == 82) return launch_prefill_wg_cfg<D, G, 8, 8>(p, max_extend_len, st);
-        return launch_prefill_wg_cfg<D, G, 4, 8>(p, max_extend_len, st);
+        if (cfg == 42) return launch_prefill_wg_cfg<D, G, 4, 8>(p, max_extend_len, st);
+        return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
     } else {
         if (cfg == 82) return launch_prefill_wg_cfg<D, G, 8, 8>(p, max_extend_len, st);
         return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);

@@ -52,10 +52,12 @@ lib.m355dbg_set_prefill_stamp_buffer(None)
 s = stamps.cpu().numpy().astype(np.float64)
 live = s[:, 7] > 0
 a = s[live]
-names = ["dma wait+barrier", "issue next pair", "K reads + QK issue", "mask/max/decide", "exp + PV", "between pairs"]
+names = ["dma wait+barrier", "slots of next pair", "K reads + QK issue", "K DMA + mask/max/decide", "V DMA + exp + PV (+drain)"]
 pairs = a[:, 7]
 print(f"waves {live.sum()}  pairs/wave median {np.median(pairs):.0f}  lifetime median {np.median(a[:, 6]):.0f} cyc")
-tot = a[:, :6].sum(axis=1)
+tot = a[:, :5].sum(axis=1)
+long = a[:, 5] > 1000
+print(f"in-kernel clock: {np.median(a[long, 6] / a[long, 5]) * 100:.0f} MHz (s_memtime / s_memrealtime, waves living > 10 us)")
 for sel_name, sel in (("all waves", np.ones(len(a), bool)), ("longest quarter", pairs >= np.percentile(pairs, 75))):
     print(f"-- {sel_name}: cycles per pair (sum over the wave / pairs of the workgroup)")
     for i, n in enumerate(names):
