@@ -18,3 +18,8 @@ timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- $BENCH 
 echo "write pass done"
 timeout -k 10 240 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
+#   4. the prefill (extend) kernel on BASELINE configs[2] (tools/bench_prefill.py): kernel stats + the tool's own line
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/prefill -o prefill -- python3 tools/bench_prefill.py --layers 8 --reps 5 > $OUT/prefill.log 2>&1
+echo "prefill stats pass done"
+timeout -k 10 240 python3 tools/bench_prefill.py > $OUT/prefill.json 2> $OUT/prefill.err
+cat $OUT/prefill.json

@@ -69,6 +69,24 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- py
        "kernels": traffic, "bench_line_same_box": bench}
 with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
+pdb = os.path.join(src, "prefill", "prefill_results.db")
+if os.path.exists(pdb):
+    db = sqlite3.connect(pdb)
+    prow = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                      "where name like '%m355::%' group by name order by sum(duration) desc").fetchall()
+    line = ""
+    pj = os.path.join(src, "prefill.json")
+    if os.path.exists(pj):
+        with open(pj) as f:
+            line = f.read().strip().splitlines()[-1]
+    with open(os.path.join(dst, f"{tag}_prefill_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 tools/bench_prefill.py --layers 8 --reps 5 (durations in ns)"])
+        w.writerow(["# un-profiled line of the same tool on the same box: " + line])
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns"])
+        for n, c, t, a, lo, hi in prow:
+            w.writerow([short(n), c, int(t), round(a, 1), int(lo), int(hi)])
+            print(f"{short(n)[:90]:90s} calls {c:5d} avg {a / 1e3:8.2f} us")
 for k, e in traffic.items():
     print(k[:90], e.get("hbm_read_bytes_per_launch"), e.get("hbm_write_bytes_per_launch"))
 for n, c, t, a, lo, hi in rows[:8]:
