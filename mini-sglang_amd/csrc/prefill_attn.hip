@@ -253,6 +253,10 @@ struct WgCfg {
 };
 
 template <int V> struct IntC { static constexpr int value = V; };
+#ifndef M355_PREFILL_PRIO
+#define M355_PREFILL_PRIO 2
+#endif
+constexpr int kPrio = M355_PREFILL_PRIO;          // s_setprio 1 around the MFMA clusters: 1 = QK^T only, 2 = PV too (each +1-2 % on cfg3, A/B on one box)
 constexpr float kLazy = 8.f;                          // log2 units
 constexpr int kSlotWin = 1024;                        // tokens whose pool slots are staged in LDS at a time
 
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+        if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {                          // S_a^T; tile b's K fragments fill in behind
             sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], qf[s], sa, 0, 0, 0);
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
             sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], qf[s], sb, 0, 0, 0);
             fa[s] = rdv(2 * pb, s);
         }
+        if (kPrio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         stamp(2);
         // the next pair's DMA goes out in the VALU-only stretches (beside LDS reads and MFMA issue a piece costs the
@@ -521,6 +527,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         for (int x = 0; x < IPW; ++x) piece(true, x, sl[x], nb);
         float sum = exp_pack(sa, pa);
         __builtin_amdgcn_sched_barrier(0);
+        if (kPrio == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {                          // O^T += V_a^T P_a^T; tile b's V^T fragments fill in behind
             o[s >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], pa[s & 1], o[s >> 1], 0, 0, 0);
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) o[s >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], pbk[s & 1], o[s >> 1], 0, 0, 0);
+        if (kPrio == 2) __builtin_amdgcn_s_setprio(0);
         l_run = fmaf(l_run, alpha, sum);
         stamp(4);
     };
