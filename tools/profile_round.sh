@@ -23,3 +23,6 @@ timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/prefill -o prefill --
 echo "prefill stats pass done"
 timeout -k 10 240 python3 tools/bench_prefill.py > $OUT/prefill.json 2> $OUT/prefill.err
 cat $OUT/prefill.json
+#   5. MFMA utilisation of the prefill kernel: one --pmc pass (5 SQ + 1 GRBM counter)
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/prefill_pmc -o pmc -- python3 tools/bench_prefill.py --layers 2 --reps 2 > $OUT/prefill_pmc.log 2>&1
+echo "prefill pmc pass done"

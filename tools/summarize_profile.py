@@ -87,6 +87,24 @@ if os.path.exists(pdb):
         for n, c, t, a, lo, hi in prow:
             w.writerow([short(n), c, int(t), round(a, 1), int(lo), int(hi)])
             print(f"{short(n)[:90]:90s} calls {c:5d} avg {a / 1e3:8.2f} us")
+ppmc = os.path.join(src, "prefill_pmc", "pmc_results.db")
+if os.path.exists(ppmc):
+    db = sqlite3.connect(ppmc)
+    vals = {}
+    for name, cname, calls, avg in db.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                              "where kernel_name like '%prefill_wg_kernel%' group by kernel_name, counter_name"):
+        vals.setdefault(short(name), {})[cname] = avg
+    for kname, v in vals.items():
+        # SQ_VALU_MFMA_BUSY_CYCLES: cycles summed over the SIMDs (= 32 x v_mfma_f32_32x32x16_bf16 count);
+        # GRBM_GUI_ACTIVE: busy cycles summed over the 8 XCDs (MI355X_MICROARCH.md "DVFS give-back")
+        cyc = v.get("GRBM_GUI_ACTIVE", 0.0) / 8
+        v["mfma_busy_frac_of_simd_cycles"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024), 4) if cyc else None
+        v["valu_insts_per_mfma"] = round(v.get("SQ_INSTS_VALU", 0.0) / max(v.get("SQ_INSTS_MFMA", 1.0), 1.0), 2)
+    with open(os.path.join(dst, f"{tag}_prefill_pmc.json"), "w") as f:
+        json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES "
+                              "GRBM_GUI_ACTIVE -- python3 tools/bench_prefill.py --layers 2 --reps 2 (averages per launch)",
+                   "kernels": vals}, f, indent=1)
+    print(json.dumps(vals, indent=1))
 for k, e in traffic.items():
     print(k[:90], e.get("hbm_read_bytes_per_launch"), e.get("hbm_write_bytes_per_launch"))
 for n, c, t, a, lo, hi in rows[:8]:
