@@ -32,6 +32,8 @@ class ForwardMetadata:
     plan: Optional[object] = None                  # ops.DecodePlan, decode only
     cu_q: Optional[torch.Tensor] = None            # int32 [B+1], prefill only
     workspace: Optional[torch.Tensor] = None
+    ws: Optional[torch.Tensor] = None              # planned decode: the workspace of this forward ...
+    ws_key: Optional[tuple] = None                 # ... and the (B, Hq, Hkv, D) it was sized for
 
 
 def pick_decode_chunk(total_tokens: int, num_kv_heads: int) -> int:
@@ -121,7 +123,10 @@ class MI355AttnBackend:
                 md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
                                           self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
                 self._plan_buf = md.plan.buf
-            ws = self._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), q.device)
+            ws = md.ws                                 # sized once per forward (same shape in every layer)
+            if ws is None or md.ws_key != (B, Hq, Hkv, D):
+                ws = md.ws = self._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), q.device)
+                md.ws_key = (B, Hq, Hkv, D)
             return ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws,
                                            k_new=k if fuse else None, v_new=v if fuse else None)
         ws = self._ws(ops.decode_workspace_bytes(B, layer.num_heads, layer.head_dim, md.max_seq_len, md.chunk_tokens),

@@ -176,9 +176,9 @@ def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Ten
         out = torch.empty((B, Hq * D), dtype=q.dtype, device=q.device)
     if scale is None:
         scale = float(D) ** -0.5
-    need = decode_planned_workspace_bytes(B, Hq, Hkv, D, plan.capacity)
-    if workspace is None or workspace.numel() * workspace.element_size() < need:
-        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    if workspace is None:                      # (a caller's workspace is size-checked by the library itself)
+        workspace = torch.empty(decode_planned_workspace_bytes(B, Hq, Hkv, D, plan.capacity), dtype=torch.uint8,
+                                device=q.device)
     if k_new is not None:
         require_cuda(k_new, "k_new"), require_cuda(v_new, "v_new")
         k2, v2 = k_new.view(B, Hkv * D), v_new.view(B, Hkv * D)
