@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--fixed-len", type=int, default=0, help="experiment: every request has this length (with --batch)")
     ap.add_argument("--batch", type=int, default=0, help="experiment: batch size for --fixed-len")
     ap.add_argument("--layers", type=int, default=0, help="experiment: number of layers (distinct KV pools)")
+    ap.add_argument("--len-scale", type=int, default=1, help="experiment: every length x this (SURVEY 8d cfg2 'long' variant: 8)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,12 +107,14 @@ def main():
     lens0 = cfg2_lengths(args.copies or tp)          # global batch 64 * tp
     if args.fixed_len:
         lens0 = [args.fixed_len] * (args.batch or 1)
+    if args.len_scale > 1:
+        lens0 = [l * args.len_scale for l in lens0]
     if args.layers:
         L = args.layers
     B = len(lens0)
     total_steps = args.warmup + args.steps + 8
     pages_needed = sum(-(-(l + total_steps) // ps) for l in lens0) + 8
-    ctx = max(2048, args.fixed_len) + 64 + total_steps
+    ctx = max(2048 * args.len_scale, args.fixed_len) + 64 + total_steps
 
     kv = m.KVCache(size=pages_needed * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16,
                    layer_num=L, device=dev)
@@ -207,7 +210,7 @@ def main():
     bytes_launch = attn_bytes_per_layer(lens_now, Hq, Hkv, D, ps) + (kv_store_bytes_per_layer(B, Hkv, D) if fused else 0)
     achieved = bytes_launch / (us_per_launch * 1e-6) / 1e9
 
-    traffic = pmc_traffic(planned) if tp == 1 and not (args.heads or args.copies or args.fixed_len or args.layers) else None
+    traffic = pmc_traffic(planned) if tp == 1 and not (args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1) else None
 
     # ---- the layer's one collective, outside the path: o_proj's row-parallel all-reduce, timed on its own
     allreduce = None

@@ -148,13 +148,17 @@ def plan_prefill(reqs: List[Req], page_manager, kvcache) -> PrefillPlan:
 
 def plan_decode(seq_lens_host: List[int], kvcache) -> tuple:
     """Host half of Batch.prepare_for_decode (engine/batch.py:325-337): bump the lengths and pop one page for
-    every request whose new token starts a page.  Returns (new seq_lens, int32 [B] new page or -1)."""
-    new_lens = [s + 1 for s in seq_lens_host]
-    fresh = kvcache.allocate_pages_decode(new_lens)
-    if any(f is None for f in fresh):
+    every request whose new token starts a page, in batch order like the reference's per-request loop
+    (memory/kvcache.py:49-56: ceil(s/ps) - ceil((s-1)/ps) pages, i.e. one iff (s-1) % ps == 0) - vectorised, no
+    per-request Python.  Returns (new seq_lens, int32 [B] new page or -1)."""
+    lens = np.asarray(seq_lens_host, dtype=np.int64) + 1
+    need = (lens - 1) % kvcache.page_size == 0
+    pages = kvcache._allocate_pages(int(need.sum()))
+    if pages is None:
         raise RuntimeError("KV pool exhausted during decode (call check_decode_mem / retract_decode first)")
-    new_pages = np.asarray([f[0] if f else -1 for f in fresh], dtype=np.int32)
-    return new_lens, new_pages
+    new_pages = np.full(lens.shape[0], -1, dtype=np.int32)
+    new_pages[need] = pages
+    return lens.tolist(), new_pages
 
 
 def _h2d(arr: np.ndarray, device) -> torch.Tensor:

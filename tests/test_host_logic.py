@@ -125,6 +125,30 @@ def test_pool_exhaustion_is_an_error_not_a_none():
     assert kv._allocate_pages(3) is None and kv.available_page_num() == 2     # kvcache.py:60-61 behaviour kept
 
 
+def test_vectorised_decode_plan_equals_the_per_request_allocator():
+    """plan_decode (one numpy pass) hands out exactly the pages, in exactly the order, of the reference-shaped
+    per-request loop allocate_pages_decode (memory/kvcache.py:49-56), for any page size; a short pool raises."""
+    m = _m()
+    from mi355_attn.batch import plan_decode
+    rng = np.random.default_rng(5)
+    for ps in (1, 2, 4, 16, 256):
+        for _ in range(20):
+            B = int(rng.integers(1, 70))
+            lens = [int(x) for x in rng.integers(1, 5 * ps + 3, size=B)]
+            size = int(rng.integers(1, 3 * B + 2)) * ps
+            a = m.KVCache(size=size, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+            b = m.KVCache(size=size, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+            want = b.allocate_pages_decode([l + 1 for l in lens])
+            if any(w is None for w in want):
+                with pytest.raises(RuntimeError, match="exhausted"):
+                    plan_decode(lens, a)
+                continue
+            new_lens, pages = plan_decode(lens, a)
+            assert new_lens == [l + 1 for l in lens] and pages.dtype == np.int32
+            assert pages.tolist() == [w[0] if w else -1 for w in want]
+            assert a.free_pages == b.free_pages
+
+
 # ------------------------------------------------------------------------------------------------
 # radix tree against the reference traces
 # ------------------------------------------------------------------------------------------------
