@@ -73,8 +73,12 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
     if (tid == 1023) cum[B] = run < icap ? run : icap;     // the last thread's running sum is the grand total
     __syncthreads();
     const int32_t total = cum[B];
-    int32_t R = (total + nwh - 1) / nwh;
-    R = R < r_min ? r_min : (R > kRMax ? kRMax : R);
+    // one range per resident wave; when that would exceed kRMax tokens, k equal ranges per wave (k rounds of the
+    // grid-stride loop) rather than kRMax-token ranges whose count is no multiple of the wave count
+    const int32_t per_wave = (total + nwh - 1) / nwh;
+    const int32_t rounds = (per_wave + kRMax - 1) / kRMax;
+    int32_t R = rounds > 0 ? (per_wave + rounds - 1) / rounds : r_min;
+    R = R < r_min ? r_min : R;
     const int32_t n_ranges = (total + R - 1) / R;
     if (tid == 0) { plan[0] = total; plan[1] = R; plan[2] = B; plan[3] = nwh; plan[4] = n_ranges; plan[5] = plan[6] = plan[7] = 0; }
     // partials per request -> pbase
