@@ -88,10 +88,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
+    rehearse = os.environ.get("M355_BENCH_REHEARSE") == "1"            # dev: all ranks on cuda:0 over gloo (one-GPU box)
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))     # RCCL over xGMI
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))     # RCCL over xGMI
 
     import mi355_attn as m
     from mi355_attn import ops
