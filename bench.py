@@ -123,10 +123,10 @@ def main():
     ctx = max(2048 * args.len_scale, args.fixed_len) + 64 + total_steps
 
     kv = m.KVCache(size=pages_needed * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16,
-                   layer_num=L, device=dev)
+                   layer_num=L, device=dev, device_free_list=os.environ.get("M355_DEVICE_FREE_LIST", "1") != "0")
     pm = m.PageManager(page_size=ps, max_req_num=B, max_context_len=ctx // ps * ps + ps, device=dev)
     g = torch.Generator().manual_seed(0)
-    kv._free = deque(torch.randperm(pages_needed, generator=g).tolist())      # shuffled physical pages
+    kv.set_free_pages(torch.randperm(pages_needed, generator=g).tolist())     # shuffled physical pages
     gg = torch.Generator(device=dev).manual_seed(1234 + rank)
     for l in range(L):                                                           # random KV content, resident in HBM
         kv._store[l].copy_(torch.randn(kv._store[l].shape, generator=gg, device=dev, dtype=torch.float32))

@@ -83,6 +83,26 @@ int m355_decode_prepare(int32_t *page_table, int64_t pt_row_stride, const int64_
                         int32_t B, int32_t page_size, int64_t *positions, int64_t *out_cache_loc,
                         void *stream);
 
+/* The free-page FIFO mirrored on the device, so that a decode step needs no page ids from the
+ * host.  ring[capacity] holds page ids, state = {head, count} (int64).  Same order as the reference's list
+ * (memory/kvcache.py:38-67, 87-91): init = range(page_num) (clear, :87-88), pop = take n from the front
+ * (_allocate_pages, :58-65; the host keeps the ids, the device only advances), push = append at the back
+ * (_free_pages, :66-67).  All calls are ordered on `stream`. */
+int m355_page_ring_init(int32_t *ring, int64_t *state, int32_t capacity, void *stream);
+int m355_page_ring_pop(int64_t *state, int32_t capacity, int32_t n, void *stream);
+int m355_page_ring_push(int32_t *ring, int64_t *state, int32_t capacity, const int32_t *pages, int32_t n,
+                        void *stream);
+
+/* m355_decode_prepare with the allocator folded in: replaces Batch.prepare_for_decode (engine/batch.py:319-343)
+ * INCLUDING allocate_pages_decode (memory/kvcache.py:49-56).  Walking the batch in order, request b takes the next
+ * page off the ring iff seq_lens_in[b] % page_size == 0 (its new token starts a page); outputs as
+ * m355_decode_prepare; state advances by the number of pages taken.  The caller guarantees that the ring holds
+ * enough pages (the host knows count and lengths). */
+int m355_decode_prepare_ring(int32_t *page_table, int64_t pt_row_stride, const int64_t *rows,
+                             const int64_t *seq_lens_in, int64_t *seq_lens_out, const int32_t *ring,
+                             int64_t *state, int32_t capacity, int32_t B, int32_t page_size,
+                             int64_t *positions, int64_t *out_cache_loc, void *stream);
+
 /* Decode attention over the paged KV pools.  Replaces TorchNativeAttnBackend.forward_decode /
  * _run_sdpa_forward_decode (layers/attention_backends/torch_native_backend.py:121-193, 237-276)
  * minus the KV write (call m355_kv_store first on the same stream):

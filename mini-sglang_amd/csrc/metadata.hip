@@ -76,7 +76,104 @@ __global__ __launch_bounds__(256) void decode_prepare_kernel(int32_t* __restrict
     out_cache_loc[b] = (int64_t)page * ps + (pos - vpn * ps);   // batch.py:341-343
 }
 
+// ------------------------------------------------------------------------------------------------
+// Free-page FIFO kept on the device as well: ring[cap] of page ids, state = {head, count}.  Same order
+// as the host FIFO (memory/kvcache.py:38-67: pop from the front, give back at the back), so the pages a decode step
+// hands out here are exactly the ones the host allocator would have handed out, request by request in batch order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void page_ring_init_kernel(int32_t* __restrict__ ring, int64_t* __restrict__ state, int32_t cap) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) ring[i] = i;   // kvcache.py:87-88
+    if (blockIdx.x == 0 && threadIdx.x == 0) { state[0] = 0; state[1] = cap; }
+}
+
+__global__ void page_ring_pop_kernel(int64_t* __restrict__ state, int32_t cap, int32_t n) {
+    state[0] = (state[0] + n) % cap;
+    state[1] -= n;
+}
+
+__global__ __launch_bounds__(256) void page_ring_push_kernel(int32_t* __restrict__ ring, int64_t* __restrict__ state, int32_t cap,
+                                                             const int32_t* __restrict__ pages, int32_t n) {
+    const int64_t tail = (state[0] + state[1]) % cap;
+    __syncthreads();                                      // everyone has read the state before thread 0 rewrites it
+    for (int32_t i = threadIdx.x; i < n; i += blockDim.x) ring[(tail + i) % cap] = pages[i];   // kvcache.py:67
+    if (threadIdx.x == 0) state[1] += n;
+}
+
+// One workgroup walks the batch in order: a request whose new token starts a page takes the next page off the ring
+// (engine/batch.py:325-343 with memory/kvcache.py:49-56 folded in); everything else is decode_prepare_kernel.
+__global__ __launch_bounds__(1024) void decode_prepare_ring_kernel(int32_t* __restrict__ page_table, int64_t pt_stride,
+                                                                   const int64_t* __restrict__ rows, const int64_t* seq_lens_in,
+                                                                   int64_t* seq_lens_out, const int32_t* __restrict__ ring,
+                                                                   int64_t* __restrict__ state, int32_t cap, int32_t B, int32_t ps,
+                                                                   int64_t* __restrict__ positions,
+                                                                   int64_t* __restrict__ out_cache_loc) {
+    __shared__ int32_t wave_sum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t head = state[0];
+    int32_t taken = 0;                                    // pages handed out to requests before this round of 1024
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + tid;
+        const int64_t pos = b < B ? seq_lens_in[b] : 1;   // old length = position of the new token
+        const bool need = b < B && pos % ps == 0;         // ceil((pos+1)/ps) - ceil(pos/ps) == 1
+        const unsigned long long mask = __ballot(need);
+        if (lane == 0) wave_sum[wv] = __popcll(mask);
+        __syncthreads();
+        int32_t before = taken, total = 0;
+        for (int k = 0; k < 16; ++k) { if (k < wv) before += wave_sum[k]; total += wave_sum[k]; }
+        before += __popcll(mask & ((1ull << lane) - 1));
+        if (b < B) {
+            const int64_t vpn = pos / ps;
+            int32_t* entry = page_table + rows[b] * pt_stride + vpn;
+            int32_t page;
+            if (need) { page = ring[(head + before) % cap]; *entry = page; }
+            else page = *entry;
+            seq_lens_out[b] = pos + 1;
+            positions[b] = pos;
+            out_cache_loc[b] = (int64_t)page * ps + (pos - vpn * ps);
+        }
+        taken += total;
+        __syncthreads();                                  // wave_sum is rewritten next round
+    }
+    if (tid == 0) { state[0] = (head + taken) % cap; state[1] -= taken; }
+}
+
 }  // namespace m355
+
+extern "C" int m355_page_ring_init(int32_t* ring, int64_t* state, int32_t capacity, void* stream) {
+    if (!ring || !state || capacity <= 0) return M355_ERR_INVALID_ARG;
+    int blocks = (capacity + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(m355::page_ring_init_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ring, state, capacity);
+    return m355::check_launch();
+}
+
+extern "C" int m355_page_ring_pop(int64_t* state, int32_t capacity, int32_t n, void* stream) {
+    if (n == 0) return M355_OK;
+    if (!state || capacity <= 0 || n < 0 || n > capacity) return M355_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(m355::page_ring_pop_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, capacity, n);
+    return m355::check_launch();
+}
+
+extern "C" int m355_page_ring_push(int32_t* ring, int64_t* state, int32_t capacity, const int32_t* pages, int32_t n,
+                                   void* stream) {
+    if (n == 0) return M355_OK;
+    if (!ring || !state || !pages || capacity <= 0 || n < 0 || n > capacity) return M355_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(m355::page_ring_push_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ring, state, capacity, pages, n);
+    return m355::check_launch();
+}
+
+extern "C" int m355_decode_prepare_ring(int32_t* page_table, int64_t pt_row_stride, const int64_t* rows,
+                                        const int64_t* seq_lens_in, int64_t* seq_lens_out, const int32_t* ring,
+                                        int64_t* state, int32_t capacity, int32_t B, int32_t page_size, int64_t* positions,
+                                        int64_t* out_cache_loc, void* stream) {
+    if (B == 0) return M355_OK;
+    if (!page_table || !rows || !seq_lens_in || !seq_lens_out || !ring || !state || !positions || !out_cache_loc || B < 0 ||
+        page_size <= 0 || pt_row_stride <= 0 || capacity <= 0)
+        return M355_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(m355::decode_prepare_ring_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, page_table, pt_row_stride,
+                       rows, seq_lens_in, seq_lens_out, ring, state, capacity, B, page_size, positions, out_cache_loc);
+    return m355::check_launch();
+}
 
 extern "C" int m355_out_cache_loc(const int32_t* page_table, int64_t pt_row_stride, const int64_t* row_of_token,
                                   const int64_t* positions, int32_t page_size, int64_t n, int64_t* out, void* stream) {

@@ -220,12 +220,21 @@ class Batch:
         self.mode = Mode.DECODE
         if self.seq_lens_host is None:
             self.seq_lens_host = [int(x) for x in self.seq_lens.tolist()]
-        self.seq_lens_host, new_pages = plan_decode(self.seq_lens_host, self.kvcache)
         self.input_ids = self.output_ids
         self.output_ids = None
-        self.seq_lens, self.positions, self.out_cache_loc = ops.decode_prepare(
-            self.page_manager.page_table, self.page_table_ids, self.seq_lens, _h2d(new_pages, self.device),
-            self.page_size)
+        if getattr(self.kvcache, "ring", None) is not None:
+            # device free list: the host only counts the pages this step takes (and moves its mirror of the FIFO)
+            lens = np.asarray(self.seq_lens_host, dtype=np.int64)
+            if not self.kvcache.take_on_device(int((lens % self.page_size == 0).sum())):
+                raise RuntimeError("KV pool exhausted during decode (call check_decode_mem / retract_decode first)")
+            self.seq_lens_host = (lens + 1).tolist()
+            self.seq_lens, self.positions, self.out_cache_loc = ops.decode_prepare_ring(
+                self.page_manager.page_table, self.page_table_ids, self.seq_lens, self.kvcache.ring, self.page_size)
+        else:
+            self.seq_lens_host, new_pages = plan_decode(self.seq_lens_host, self.kvcache)
+            self.seq_lens, self.positions, self.out_cache_loc = ops.decode_prepare(
+                self.page_manager.page_table, self.page_table_ids, self.seq_lens, _h2d(new_pages, self.device),
+                self.page_size)
         self.cu_q = self.row_of_token = None
 
     # ---- bookkeeping kept working (engine/batch.py:345-464)

@@ -17,7 +17,7 @@ from . import ops
 
 class KVCache:
     def __init__(self, size: int, page_size: int, head_num: int, head_dim: int, dtype: torch.dtype,
-                 layer_num: int, device: str):
+                 layer_num: int, device: str, device_free_list: bool = False):
         self.page_num = size // page_size                                   # kvcache.py:16
         self.page_size = page_size
         self.head_num = head_num
@@ -29,6 +29,9 @@ class KVCache:
         self._store = torch.zeros((layer_num, 2, rows, head_num, head_dim), dtype=dtype, device=device)
         self.k_cache = [self._store[l, 0] for l in range(layer_num)]        # kvcache.py:24-35 shapes
         self.v_cache = [self._store[l, 1] for l in range(layer_num)]
+        # optional device mirror of the FIFO: decode steps then allocate inside their metadata kernel
+        self.ring = ops.PageRing(self.page_num, device) if device_free_list else None
+        self._ring_defer = None                    # pops batched into one launch while a prefill allocates
         self.clear()
 
     # ---- free-page FIFO: pop from the front, return to the back (kvcache.py:38-67, 87-91)
@@ -38,7 +41,13 @@ class KVCache:
 
     def allocate_pages_prefill(self, seq_lens: Sequence[int], prefix_lens: Sequence[int]) -> List[Optional[List[int]]]:
         ps = self.page_size
-        return [self._allocate_pages(-(-int(s) // ps) - -(-int(p) // ps)) for s, p in zip(seq_lens, prefix_lens)]
+        self._ring_defer = 0
+        try:
+            return [self._allocate_pages(-(-int(s) // ps) - -(-int(p) // ps)) for s, p in zip(seq_lens, prefix_lens)]
+        finally:
+            n, self._ring_defer = self._ring_defer, None
+            if self.ring is not None:
+                self.ring.pop(n)
 
     def allocate_pages_decode(self, seq_lens: Sequence[int]) -> List[Optional[List[int]]]:
         return self.allocate_pages_prefill(seq_lens, [int(s) - 1 for s in seq_lens])
@@ -46,15 +55,40 @@ class KVCache:
     def _allocate_pages(self, num_pages: int) -> Optional[List[int]]:
         if num_pages > len(self._free):
             return None                                                     # kvcache.py:60-61
+        if self.ring is not None:
+            if self._ring_defer is None:
+                self.ring.pop(num_pages)
+            else:
+                self._ring_defer += num_pages
         return [self._free.popleft() for _ in range(num_pages)]
+
+    def take_on_device(self, num_pages: int) -> bool:
+        """The decode metadata kernel takes `num_pages` off the device ring itself: only the host mirror moves here.
+        False (nothing taken) when the pool is short."""
+        if num_pages > len(self._free):
+            return False
+        for _ in range(num_pages):
+            self._free.popleft()
+        return True
 
     def _free_pages(self, pages: Iterable[int]) -> None:
         if isinstance(pages, torch.Tensor):
             pages = pages.tolist()
-        self._free.extend(int(p) for p in pages)
+        pages = [int(p) for p in pages]
+        self._free.extend(pages)
+        if self.ring is not None:
+            self.ring.push(pages)
 
     def clear(self) -> None:
         self._free = deque(range(self.page_num))
+        if self.ring is not None:
+            self.ring.reset()
+
+    def set_free_pages(self, pages: Iterable[int]) -> None:
+        """Replace the FIFO content, front to back (benchmarks: shuffled physical pages)."""
+        self._free = deque(int(p) for p in pages)
+        if self.ring is not None:
+            self.ring.load(list(self._free))
 
     def available_page_num(self) -> int:
         return len(self._free)

@@ -90,6 +90,67 @@ def decode_prepare(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: torch
     return trio[0], trio[1], trio[2]
 
 
+class PageRing:
+    """The free-page FIFO mirrored on the device (m355_page_ring_*): ring [capacity] int32, state {head, count} int64."""
+
+    def __init__(self, capacity: int, device):
+        self.capacity = int(capacity)
+        self.ring = torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self.state = torch.empty(2, dtype=torch.int64, device=device)
+        self.reset()
+
+    def reset(self) -> None:
+        check(_lib.load().m355_page_ring_init(self.ring.data_ptr(), self.state.data_ptr(), self.capacity,
+                                              current_stream()), "m355_page_ring_init")
+
+    def load(self, pages) -> None:
+        """Replace the content: `pages` front to back (benchmarks hand pages out in a shuffled order)."""
+        t = torch.as_tensor(pages, dtype=torch.int32)
+        assert t.numel() <= self.capacity
+        self.ring[: t.numel()].copy_(t)
+        self.state.copy_(torch.tensor([0, t.numel()], dtype=torch.int64))
+
+    def pop(self, n: int) -> None:
+        """The host allocator took n pages off the front (it keeps their ids)."""
+        if n:
+            check(_lib.load().m355_page_ring_pop(self.state.data_ptr(), self.capacity, int(n), current_stream()),
+                  "m355_page_ring_pop")
+
+    def push(self, pages) -> None:
+        """Pages given back, appended in this order."""
+        t = torch.as_tensor(pages, dtype=torch.int32)
+        if t.numel() == 0:
+            return
+        if t.device != self.ring.device:
+            t = (t.pin_memory() if torch.cuda.is_available() else t).to(self.ring.device, non_blocking=True)
+        check(_lib.load().m355_page_ring_push(self.ring.data_ptr(), self.state.data_ptr(), self.capacity, t.data_ptr(),
+                                              t.numel(), current_stream()), "m355_page_ring_push")
+
+    def snapshot(self):
+        """(free page ids front to back) - a device sync; tests and debugging only."""
+        head, count = (int(x) for x in self.state.tolist())
+        idx = (head + torch.arange(count, device=self.ring.device)) % self.capacity
+        return self.ring[idx].tolist()
+
+
+def decode_prepare_ring(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: torch.Tensor, ring: PageRing,
+                        page_size: int):
+    """decode_prepare with the page allocation done by the kernel from the device FIFO (m355_decode_prepare_ring):
+    no page ids cross PCIe.  Returns (new_seq_lens, positions, out_cache_loc)."""
+    lib = _lib.load()
+    for n, t in (("page_table", page_table), ("rows", rows), ("seq_lens", seq_lens)):
+        require_cuda(t, n)
+    assert rows.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    assert seq_lens.is_contiguous() and rows.is_contiguous()
+    B = seq_lens.numel()
+    trio = torch.empty((3, B), dtype=torch.int64, device=seq_lens.device)     # new seq_lens | positions | loc
+    check(lib.m355_decode_prepare_ring(page_table.data_ptr(), page_table.stride(0), rows.data_ptr(), seq_lens.data_ptr(),
+                                       trio[0].data_ptr(), ring.ring.data_ptr(), ring.state.data_ptr(), ring.capacity,
+                                       B, page_size, trio[1].data_ptr(), trio[2].data_ptr(), current_stream()),
+          "m355_decode_prepare_ring")
+    return trio[0], trio[1], trio[2]
+
+
 def decode_workspace_bytes(B: int, Hq: int, D: int, max_seq_len: int, chunk_tokens: int = 0) -> int:
     return int(_lib.load().m355_decode_workspace_bytes(B, Hq, D, max_seq_len, chunk_tokens))
 

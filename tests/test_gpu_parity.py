@@ -28,14 +28,17 @@ def _mods():
     return mi355_attn, ops
 
 
+@pytest.mark.parametrize("device_free_list", [False, True], ids=["host_fifo", "device_ring"])
 @pytest.mark.parametrize("path", flow_fixtures(), ids=fixture_id)
-def test_flow_through_backend(path):
+def test_flow_through_backend(path, device_free_list):
     """prefill -> extend over cached prefix -> decode steps, driven through Batch + MI355AttnBackend exactly as
-    bench_one_batch drives the reference (bench_one_batch.py:195-259)."""
+    bench_one_batch drives the reference (bench_one_batch.py:195-259).  With the device free list the decode steps
+    take their pages inside the metadata kernel; every page id must still be the reference's."""
     m, ops = _mods()
     fr = FlowReplay(path, torch.bfloat16)
     ps, Hq, Hkv, D = fr.ps, fr.Hq, fr.Hkv, fr.D
-    kv = m.KVCache(size=fr.S_pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=1, device=DEV)
+    kv = m.KVCache(size=fr.S_pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=1, device=DEV,
+                   device_free_list=device_free_list)
     pm = m.PageManager(page_size=ps, max_req_num=fr.max_req, max_context_len=fr.ctx, device=DEV)
     backend = m.MI355AttnBackend(SimpleNamespace(device=DEV, page_size=ps, kvcache=kv, page_manager=pm))
     layer = m.Attention(layer_id=0, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=D ** -0.5)
@@ -65,6 +68,8 @@ def test_flow_through_backend(path):
         rows = pm.page_table[batch.page_table_ids, :used].cpu().numpy()
         assert np.array_equal(rows, fr.golden(ph.tag, "page_rows")), ph.tag
         assert kv.free_pages[:4] == [int(x) for x in fr.golden(ph.tag, "free_head")]
+        if device_free_list:
+            assert kv.ring.snapshot() == kv.free_pages, ph.tag       # the device FIFO is the host FIFO
         # ---- attention (writes K/V first)
         qkv = ph.qkv.to(DEV)
         q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
@@ -81,6 +86,68 @@ def test_flow_through_backend(path):
         np.testing.assert_allclose(o.float().cpu().numpy()[rows_], ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=ph.tag)
         np.testing.assert_allclose(o.float().cpu().numpy(), ph.out.float().numpy(), rtol=BF16_RTOL, atol=BF16_ATOL,
                                    err_msg=ph.tag + " vs oracle bf16")
+
+
+def test_device_page_ring_follows_the_host_fifo():
+    """Random serving trace - prefills, decode steps over page boundaries, finished requests giving pages back in
+    odd orders, wrap-around of the ring - with the device free list against the same trace on the host FIFO:
+    identical page tables, slots and free lists at every step (memory/kvcache.py:38-67 order)."""
+    m, ops = _mods()
+    rng = np.random.default_rng(11)
+    for ps in (1, 4, 16):
+        pages = 96
+        kvs = [m.KVCache(size=pages * ps, page_size=ps, head_num=1, head_dim=64, dtype=torch.bfloat16, layer_num=1, device=DEV,
+                         device_free_list=flag) for flag in (False, True)]
+        pms = [m.PageManager(page_size=ps, max_req_num=16, max_context_len=64 * ps, device=DEV) for _ in range(2)]
+        live = [[], []]                                              # per variant: list of (req, batch-of-one bookkeeping)
+        batches = [None, None]
+        rid = 0
+        for step in range(60):
+            action = rng.integers(0, 4)
+            if action == 0 or batches[0] is None or not batches[0].reqs:
+                n_new = int(rng.integers(1, 4))
+                lens = [int(x) for x in rng.integers(1, 3 * ps + 2, size=n_new)]
+                if kvs[0].available_page_num() < sum(-(-l // ps) for l in lens) + 8 or len(batches[0].reqs if batches[0] else []) + n_new > 12:
+                    continue
+                for v in range(2):
+                    reqs = [m.Req(rid + i, list(range(l))) for i, l in enumerate(lens)]
+                    for r in reqs:
+                        r.fill_ids = list(r.origin_input_ids)
+                    nb = m.Batch(reqs, page_manager=pms[v], kvcache=kvs[v], device=DEV)
+                    nb.prepare_for_prefill()
+                    if batches[v] is None or not batches[v].reqs:
+                        batches[v] = nb
+                    else:
+                        batches[v].merge_batch(nb)
+                rid += n_new
+            elif action == 1 and len(batches[0].reqs) > 1:
+                # a request finishes: its pages go back (reference scheduler: free the row's pages, then the row)
+                j = int(rng.integers(0, len(batches[0].reqs)))
+                for v in range(2):
+                    b = batches[v]
+                    row = int(b.page_table_ids[j])
+                    n_pg = -(-b._lens_host()[j] // ps)
+                    kvs[v]._free_pages(pms[v].page_table[row, :n_pg])
+                    pms[v].free([row])
+                    b.input_ids = b.output_ids = None               # (stale after merge_batch; not part of this test)
+                    b.filter_batch([i for i in range(len(b.reqs)) if i != j])
+            else:
+                if kvs[0].available_page_num() < len(batches[0].reqs):
+                    continue
+                for v in range(2):
+                    b = batches[v]
+                    b.output_ids = torch.zeros(len(b.reqs), dtype=torch.int64, device=DEV)
+                    b.prepare_for_decode()
+            a, b = batches
+            if a is None:
+                continue
+            assert torch.equal(a.seq_lens, b.seq_lens) and torch.equal(a.page_table_ids, b.page_table_ids)
+            if a.out_cache_loc is not None and b.out_cache_loc is not None:
+                assert torch.equal(a.out_cache_loc, b.out_cache_loc), (ps, step)
+                assert torch.equal(a.positions, b.positions)
+            used = -(-max(a._lens_host()) // ps)
+            assert torch.equal(pms[0].page_table[a.page_table_ids, :used], pms[1].page_table[b.page_table_ids, :used]), (ps, step)
+            assert kvs[0].free_pages == kvs[1].free_pages == kvs[1].ring.snapshot(), (ps, step)
 
 
 def test_kv_store_edges():

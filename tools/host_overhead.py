@@ -16,7 +16,7 @@ import mi355_attn as m  # noqa: E402
 
 dev = "cuda:0"
 Hq, Hkv, D, ps, L, B, LEN = 32, 8, 64, 16, 16, int(os.environ.get("HB", "1")), 128
-kv = m.KVCache(max(4096, B * 512), ps, Hkv, D, torch.bfloat16, L, dev)
+kv = m.KVCache(max(4096, B * 512), ps, Hkv, D, torch.bfloat16, L, dev, device_free_list=os.environ.get("HRING") == "1")
 pm = m.PageManager(ps, max(B, 8), 4096, dev)
 reqs = [m.Req(i, list(range(LEN))) for i in range(B)]
 for r in reqs:
