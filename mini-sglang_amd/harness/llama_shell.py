@@ -129,7 +129,8 @@ class HarnessRunner:
         self.model = SyntheticLlama(shape, tp_rank, tp_size, device, dtype, seed, max_position=max(context_len + 8, 64))
         size = max_total_tokens // page_size * page_size                                    # model_runner.py:141-145
         self.kvcache = m.KVCache(size=size, page_size=page_size, head_num=self.model.heads.num_kv_heads,
-                                 head_dim=shape.head_dim, dtype=dtype, layer_num=shape.layers, device=device)
+                                 head_dim=shape.head_dim, dtype=dtype, layer_num=shape.layers, device=device,
+                                 device_free_list=str(device).startswith("cuda"))
         self.page_manager = m.PageManager(page_size=page_size, max_req_num=max_reqs, max_context_len=context_len + 4,
                                           device=device)
         self.attn_backend = m.MI355AttnBackend(self)                                        # model_runner.py:90-91
