@@ -353,7 +353,7 @@ def test_decode_attn_softmax_spike():
     np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
 
 
-@pytest.mark.parametrize("Hq,Hkv,D,ps", [(32, 8, 64, 16), (32, 8, 128, 16), (8, 1, 128, 1), (16, 4, 128, 256)])
+@pytest.mark.parametrize("Hq,Hkv,D,ps", [(32, 8, 64, 16), (32, 8, 128, 16), (8, 1, 128, 1), (16, 4, 128, 256), (8, 2, 128, 12), (4, 2, 64, 3)])
 def test_prefill_attn_ragged_prefix(Hq, Hkv, D, ps):
     """Mixed zero / non-zero / non-page-aligned-length prefixes, extends of 1..300 tokens."""
     m, ops = _mods()

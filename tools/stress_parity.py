@@ -43,7 +43,7 @@ while time.time() - t0 < budget:
     G = int(rng.choice([1, 2, 4, 8]))
     D = int(rng.choice([64, 128]))
     Hq = Hkv * G
-    ps = int(rng.choice([1, 4, 16, 64]))
+    ps = int(rng.choice([1, 3, 4, 12, 16, 64]))
     B = int(rng.choice([1, 2, 7, 33, 150]))
     mode = rng.choice(["short", "mixed", "long"])
     hi = {"short": 40, "mixed": 700, "long": 3000}[mode]
