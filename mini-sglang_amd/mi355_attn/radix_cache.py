@@ -250,3 +250,105 @@ class PagedRadixCache:
             else:
                 stack.extend(n.children.values())
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# native tree: same interface, the walks run in libmi355radix.so (include/mi355radix.h)
+# ------------------------------------------------------------------------------------------------
+_RADIX_LIB = None
+
+
+def _radix_lib():
+    global _RADIX_LIB
+    if _RADIX_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libmi355radix.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it (make -C mini-sglang_amd/csrc_host, or __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        i64, p = ctypes.c_int64, ctypes.c_void_p
+        for name, res, args in (
+                ("m355r_version", ctypes.c_int, []),
+                ("m355r_create", p, [ctypes.c_int32]), ("m355r_destroy", None, [p]), ("m355r_reset", None, [p]),
+                ("m355r_match_prefix", i64, [p, p, i64, p, i64, p]),
+                ("m355r_last_match", i64, [p, p, i64]),
+                ("m355r_insert", i64, [p, p, i64, p, i64]),
+                ("m355r_inc_lock_ref", i64, [p, i64]), ("m355r_dec_lock_ref", i64, [p, i64]),
+                ("m355r_evict", i64, [p, i64, p, i64]),
+                ("m355r_evictable_size", i64, [p]), ("m355r_protected_size", i64, [p]),
+                ("m355r_total_size", i64, [p]), ("m355r_node_count", i64, [p])):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _RADIX_LIB = lib
+    return _RADIX_LIB
+
+
+class NativeRadixCache(PagedRadixCache):
+    """PagedRadixCache with the tree in native code.  Nodes are opaque integer handles (`req.last_node` holds one);
+    the request life-cycle methods are inherited and call the primitives below."""
+
+    def __init__(self, page_manager, kvcache, page_size: Optional[int] = None):
+        import numpy as np
+        self._np = np
+        self._lib = _radix_lib()
+        ps = page_size if page_size is not None else page_manager.page_size
+        self._tree = self._lib.m355r_create(int(ps))
+        super().__init__(page_manager, kvcache, page_size)
+
+    def __del__(self):
+        tree, self._tree = getattr(self, "_tree", None), None
+        if tree:
+            self._lib.m355r_destroy(tree)
+
+    def reset(self) -> None:
+        import ctypes
+        self._lib.m355r_reset(self._tree)
+        node = ctypes.c_int64(0)
+        self._lib.m355r_match_prefix(self._tree, None, 0, None, 0, ctypes.byref(node))
+        self.root_node = int(node.value)
+
+    def match_prefix(self, key):
+        import ctypes
+        np = self._np
+        k = np.ascontiguousarray(np.asarray(key, dtype=np.int64))
+        cap = k.size // self.page_size
+        out = np.empty(max(cap, 1), dtype=np.int32)
+        node = ctypes.c_int64(0)
+        n = self._lib.m355r_match_prefix(self._tree, k.ctypes.data, k.size, out.ctypes.data, out.size, ctypes.byref(node))
+        if n > out.size:      # the reference's walk after a split can report more pages than the key has (see _match_walk)
+            out = np.empty(n, dtype=np.int32)
+            self._lib.m355r_last_match(self._tree, out.ctypes.data, out.size)
+        return out[:n].tolist(), int(node.value)
+
+    def insert(self, key, value=None) -> int:
+        assert value is not None, "value must be the page numbers of `key`"
+        np = self._np
+        k = np.ascontiguousarray(np.asarray(key, dtype=np.int64))
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.int32))
+        return int(self._lib.m355r_insert(self._tree, k.ctypes.data, k.size, v.ctypes.data, v.size))
+
+    def evict(self, num_pages) -> None:
+        np = self._np
+        out = np.empty(max(int(self._lib.m355r_total_size(self._tree)) // self.page_size, 1), dtype=np.int32)
+        n = int(self._lib.m355r_evict(self._tree, int(num_pages), out.ctypes.data, out.size))
+        if n > 0 and self.kvcache is not None:
+            self.kvcache._free_pages(out[:n].tolist())
+
+    def inc_lock_ref(self, node) -> int:
+        return int(self._lib.m355r_inc_lock_ref(self._tree, int(node)))
+
+    def dec_lock_ref(self, node) -> int:
+        return int(self._lib.m355r_dec_lock_ref(self._tree, int(node)))
+
+    def evictable_size(self) -> int:
+        return int(self._lib.m355r_evictable_size(self._tree))
+
+    def protected_size(self) -> int:
+        return int(self._lib.m355r_protected_size(self._tree))
+
+    def total_size(self) -> int:
+        return int(self._lib.m355r_total_size(self._tree))
+
+    def node_count(self) -> int:
+        return int(self._lib.m355r_node_count(self._tree))

@@ -157,16 +157,18 @@ def _traces():
         return json.load(f)
 
 
+@pytest.mark.parametrize("native", [False, True], ids=["python_tree", "native_tree"])
 @pytest.mark.parametrize("name", sorted(_traces().keys()))
-def test_radix_cache_trace(name):
+def test_radix_cache_trace(name, native):
     m = _m()
     from mi355_attn.batch import plan_prefill
+    from mi355_attn.radix_cache import NativeRadixCache
     tr = _traces()[name]
     ps, prompts = tr["ps"], tr["prompts"]
     ctx = (max(len(p) for p in prompts) + 8) // ps * ps + ps
     kv = m.KVCache(size=tr["n_pages"] * ps, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
     pm = m.PageManager(page_size=ps, max_req_num=len(prompts) + 1, max_context_len=ctx, device="cpu")
-    tree = m.PagedRadixCache(pm, kv)
+    tree = (NativeRadixCache if native else m.PagedRadixCache)(pm, kv)
     steps = iter(tr["steps"])
 
     def check(op, **extra):
@@ -203,6 +205,73 @@ def test_radix_cache_trace(name):
     probe = list(prompts[0]) + [1, 2, 3]
     val, _ = tree.match_prefix(probe)
     check("match", key=probe, ppns=val)
+
+
+def test_native_radix_tree_equals_the_python_tree_on_random_traffic():
+    """libmi355radix.so against mi355_attn.radix_cache.PagedRadixCache (itself pinned to the reference's traces) on
+    random insert / match / lock / unlock / evict traffic over a small alphabet (many shared prefixes, partial-page
+    matches, splits, the split-walk quirk at page_size 1): same pages, same sizes, same eviction order."""
+    from mi355_attn.radix_cache import NativeRadixCache, PagedRadixCache
+
+    class Pool:                      # records what the trees hand back
+        def __init__(self):
+            self.freed = []
+
+        def _free_pages(self, pages):
+            self.freed.extend(int(p) for p in pages)
+
+    rng = np.random.default_rng(3)
+    for ps in (1, 2, 4, 16):
+        pools = [Pool(), Pool()]
+        trees = [PagedRadixCache(None, pools[0], page_size=ps), NativeRadixCache(None, pools[1], page_size=ps)]
+        held = []                                                    # (python node, native handle) pairs that are locked
+        next_page = 0
+        for step in range(400):
+            op = rng.integers(0, 10)
+            n_tok = int(rng.integers(0, 6 * ps + 3))
+            key = [int(x) for x in rng.integers(0, 3, size=n_tok)]
+            if op < 4:
+                pages = list(range(next_page, next_page + n_tok // ps))
+                next_page += len(pages)
+                a, b = trees[0].insert(key, pages), trees[1].insert(key, pages)
+                assert a == b, (ps, step, "insert")
+            elif op < 7:
+                try:
+                    (pa, na), err = trees[0].match_prefix(key), None
+                except Exception as e:                               # (never expected; keeps the comparison honest)
+                    err = e
+                assert err is None
+                pb, nb = trees[1].match_prefix(key)
+                assert pa == pb, (ps, step, "match", key)
+                if rng.integers(0, 2) and len(held) < 6:
+                    assert trees[0].inc_lock_ref(na) == trees[1].inc_lock_ref(nb)
+                    held.append((na, nb))
+            elif op < 8 and held:
+                na, nb = held.pop(int(rng.integers(0, len(held))))
+                assert trees[0].dec_lock_ref(na) == trees[1].dec_lock_ref(nb)
+            else:
+                k = int(rng.integers(1, 6))
+                trees[0].evict(k)
+                trees[1].evict(k)
+                assert pools[0].freed == pools[1].freed, (ps, step, "evict order")
+            sizes = [(t.evictable_size(), t.protected_size(), t.total_size()) for t in trees]
+            assert sizes[0] == sizes[1], (ps, step, sizes)
+        trees[0].evict(10 ** 6)
+        trees[1].evict(10 ** 6)
+        assert pools[0].freed == pools[1].freed
+
+
+def test_native_radix_library_exports_its_header():
+    import ctypes
+    import re
+    hdr = open(os.path.join(REPO, "include", "mi355radix.h")).read()
+    names = sorted(set(re.findall(r"\b(m355r_[a-z_]+)\s*\(", hdr)))
+    assert len(names) >= 12
+    lib = ctypes.CDLL(os.path.join(REPO, "mini-sglang_amd", "lib", "libmi355radix.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.m355r_version.restype = ctypes.c_int
+    assert lib.m355r_version() == 1
 
 
 def test_decode_chunk_heuristic_bounds():
