@@ -182,10 +182,16 @@ def main():
     ba = BenchArgs(**{f.name: (tuple(getattr(a, f.name)) if isinstance(getattr(a, f.name), (list, tuple)) else getattr(a, f.name))
                       for f in dataclasses.fields(BenchArgs)})
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    rehearse = os.environ.get("M355_BENCH_REHEARSE") == "1"      # dev: every rank on cuda:0, gloo (a one-GPU box)
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
     rank_print = print if rank == 0 else (lambda *x, **k: None)
     shape = SHAPES[ba.model]
     max_bs, max_len = max(ba.batch_size), max(ba.input_len) + max(ba.output_len) + ba.page_size

@@ -54,3 +54,21 @@ def test_latency_mode_emits_the_result_record(tmp_path):
     runner = HarnessRunner(SHAPES["tiny"], 16, max_total_tokens=4096, max_reqs=2, context_len=128)
     res = bob.latency_test(runner, bob.BenchArgs(model="tiny"), 2, 64, 4, lambda *a, **k: None, 1)
     assert res["batch_size"] == 2 and res["decode_throughput"] > 0 and res["prefill_latency"] > 0
+
+
+def test_tp2_rehearsal_matches_tp1_first_tokens():
+    """The head-sharded path end to end (models/llama.py:76-87 sharding, layers/linear.py:228-232 all-reduces): two
+    ranks of bench_one_batch on this one GPU over gloo pass the three-phase correctness test, and the first token
+    each prompt generates is the single-GPU one (later tokens may part ways: bf16 sums in a different order)."""
+    import re
+    import subprocess
+    script = os.path.join(os.path.dirname(HERE), "mini-sglang_amd", "bench_one_batch.py")
+    args = ["--model", "tiny", "--correctness-test", "--batch-size", "3", "--input-len", "70", "--output-len", "6", "--cut-len", "32"]
+    env = dict(os.environ, M355_BENCH_REHEARSE="1")
+    one = subprocess.run([sys.executable, script] + args, capture_output=True, text=True, timeout=300)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29517", script] + args, capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0 and "correctness: PASS" in one.stdout, one.stdout[-2000:] + one.stderr[-2000:]
+    assert two.returncode == 0 and "correctness: PASS" in two.stdout, two.stdout[-2000:] + two.stderr[-2000:]
+    first = lambda out: [int(x) for x in re.findall(r"Prompt \d+ =+ \[(\d+)", out)]
+    assert len(first(one.stdout)) == 3 and first(one.stdout) == first(two.stdout)
