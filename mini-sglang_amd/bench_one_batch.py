@@ -51,6 +51,7 @@ class BenchArgs:                                    # bench_one_batch.py:72-84
     cut_len: int = 4
     model: str = "llama-3-8b"
     page_size: int = 16
+    graph: bool = False                             # decode steps replayed from one captured HIP graph (GraphedDecode)
 
     @staticmethod
     def add_cli_args(p: argparse.ArgumentParser):
@@ -63,6 +64,7 @@ class BenchArgs:                                    # bench_one_batch.py:72-84
         p.add_argument("--cut-len", type=int, default=BenchArgs.cut_len)
         p.add_argument("--model", type=str, default=BenchArgs.model, choices=sorted(SHAPES))
         p.add_argument("--page-size", type=int, default=BenchArgs.page_size)
+        p.add_argument("--graph", action="store_true", help="decode through one captured HIP graph per run (single GPU)")
 
 
 def synth_prompts(batch_size: int, input_len: int, vocab: int, seed: int = 0) -> List[List[int]]:
@@ -96,13 +98,75 @@ def decode(input_token_ids, batch, runner):         # bench_one_batch.py:207-214
     return next_ids, logits
 
 
+class GraphedDecode:
+    """The decode loop with one step - metadata kernel, every layer, greedy sampling - captured ONCE as a HIP graph and
+    replayed: a decode step at small batch is a few hundred launches of a few microseconds each, i.e. bound by the
+    host's launch rate.  Possible because nothing in the path allocates, synchronises or needs host data per step:
+    pages come from the device free list (m355_decode_prepare_ring), lengths / positions / slots / token ids live in
+    fixed buffers that the step updates in place, and the plan is laid out once for the final token count.  The host
+    only moves its mirrors (Batch.advance_host_for_decode).  Same kernels, same order: tokens identical to decode()."""
+
+    def __init__(self, first_ids, batch, runner, n_steps: int):
+        assert runner.kvcache.ring is not None, "graph mode needs KVCache(device_free_list=True)"
+        assert runner.tp_size == 1, "graph mode is single-GPU here"
+        self.batch, self.runner = batch, runner
+        B = len(batch.reqs)
+        dev = first_ids.device
+        self.ids = first_ids.clone()
+        self.seq_lens = batch.seq_lens.clone()
+        self.pos, self.loc = torch.empty_like(self.seq_lens), torch.empty_like(self.seq_lens)
+        self.out = torch.zeros((B, max(n_steps, 1)), dtype=torch.int64, device=dev)
+        self.step = torch.zeros((1, 1), dtype=torch.int64, device=dev)
+        batch.mode = m.Mode.DECODE
+        batch.input_ids, batch.output_ids = self.ids, None
+        batch.seq_lens, batch.positions, batch.out_cache_loc = self.seq_lens, self.pos, self.loc
+        batch.cu_q = batch.row_of_token = None
+        runner.attn_backend.decode_capacity_hint = sum(batch._lens_host()) + B * (n_steps + 1)
+        self.taken = 0
+        # step 1 eagerly on a side stream (allocator pools, workspaces, plan buffer, library handles) ...
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            batch.advance_host_for_decode()
+            self._device_step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.taken += 1
+        # ... then step 2 is captured (nothing runs during capture) and run by its first replay
+        self.graph = torch.cuda.CUDAGraph()
+        if n_steps >= 2:
+            batch.advance_host_for_decode()
+            with torch.cuda.graph(self.graph):
+                self._device_step()
+            self.graph.replay()
+            self.taken += 1
+
+    @torch.no_grad()
+    def _device_step(self):
+        b, r = self.batch, self.runner
+        m.ops.decode_prepare_ring(r.page_manager.page_table, b.page_table_ids, self.seq_lens, r.kvcache.ring, r.page_size,
+                                  out=(self.seq_lens, self.pos, self.loc))
+        _, nxt = r.forward(b)
+        self.ids.copy_(nxt)
+        self.out.scatter_(1, self.step.expand(self.out.shape[0], 1), nxt.unsqueeze(1))
+        self.step += 1
+
+    def next(self):
+        """One more decode step (host mirrors + one graph launch)."""
+        self.batch.advance_host_for_decode()
+        self.graph.replay()
+        self.taken += 1
+
+    def tokens(self) -> torch.Tensor:
+        return self.out[:, : self.taken]
+
+
 def reset_pools(runner):
     """All pages and page-table rows back to their free lists (the harness owns every request)."""
     runner.kvcache.clear()
     runner.page_manager.clear()
 
 
-def three_phase(runner, prompts, cut_len: int, output_len: int):
+def three_phase(runner, prompts, cut_len: int, output_len: int, graph: bool = False):
     """prefill(cut) -> extend over the cached prefix -> decode; returns (final prefill logits, generated ids [B, output_len])."""
     ps = runner.page_size
     reqs = make_reqs(prompts, upto=cut_len)
@@ -114,6 +178,11 @@ def three_phase(runner, prompts, cut_len: int, output_len: int):
         r.fill_ids = r.fill_ids + list(prompts[i][cut_len:])
         r.prefix_ppns = runner.page_manager.page_table[r.page_table_id, : cut_len // ps].tolist() if cut_len > 0 else []
     next_ids, logits, batch = extend(reqs, runner)
+    if graph and output_len > 1:
+        g = GraphedDecode(next_ids, batch, runner, output_len - 1)
+        while g.taken < output_len - 1:
+            g.next()
+        return logits, torch.cat([next_ids.unsqueeze(1), g.tokens()], dim=1)
     out = [next_ids]
     for _ in range(output_len - 1):
         next_ids, _ = decode(next_ids, batch, runner)
@@ -138,6 +207,13 @@ def correctness_test(runner, bench_args: BenchArgs, rank_print):
     rank_print(f"greedy tokens agree: {100 * same:.1f}%")
     for i in range(min(B, 3)):
         rank_print(f"========== Prompt {i} ========== {ids3[i].tolist()}")
+    if bench_args.graph:
+        reset_pools(runner)
+        _, idsg = three_phase(runner, prompts, bench_args.cut_len, bench_args.output_len[0], graph=True)
+        gsame = bool(torch.equal(idsg, ids3))
+        rank_print(f"graphed decode tokens identical to the eager loop: {gsame}")
+        if not gsame:
+            same = 0.0
     return err, ref, same
 
 
@@ -154,12 +230,25 @@ def latency_test(runner, bench_args: BenchArgs, bs: int, il: int, ol: int, rank_
         sync()
         prefill = time.perf_counter() - t0
         steps = []
-        for _ in range(ol - 1):
+        if bench_args.graph and ol > 3:
             t0 = time.perf_counter()
-            next_ids, _ = decode(next_ids, batch, runner)
+            g = GraphedDecode(next_ids, batch, runner, ol - 1)       # runs steps 1 and 2 (eager warm-up, capture + replay)
             sync()
-            steps.append(time.perf_counter() - t0)
-        total_decode = sum(steps)
+            setup = time.perf_counter() - t0
+            while g.taken < ol - 1:
+                t0 = time.perf_counter()
+                g.next()
+                sync()
+                steps.append(time.perf_counter() - t0)
+            total_decode = sum(steps) / len(steps) * (ol - 1)        # the two set-up steps priced as replayed steps
+        else:
+            setup = None
+            for _ in range(ol - 1):
+                t0 = time.perf_counter()
+                next_ids, _ = decode(next_ids, batch, runner)
+                sync()
+                steps.append(time.perf_counter() - t0)
+            total_decode = sum(steps)
         result = {
             "run_name": bench_args.run_name, "model": shape.name, "tp_size": tp_size, "page_size": runner.page_size,
             "batch_size": bs, "input_len": il, "output_len": ol, "weights": "synthetic", "dtype": "bf16",
@@ -169,6 +258,7 @@ def latency_test(runner, bench_args: BenchArgs, bs: int, il: int, ol: int, rank_
             "total_decode_latency": total_decode,
             "decode_throughput": bs * (ol - 1) / total_decode if steps else None,
             "total_latency": prefill + total_decode, "overall_throughput": bs * (il + ol) / (prefill + total_decode),
+            "decode_graph": bool(setup is not None), "graph_setup_latency": setup,
         }
     reset_pools(runner)
     rank_print(json.dumps(result))

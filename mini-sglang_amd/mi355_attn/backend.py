@@ -63,6 +63,9 @@ class MI355AttnBackend:
         self.fused_store = (os.environ.get("M355_STREAM_KERNEL", "mfma")[:1] != "v"
                             and os.environ.get("M355_DECODE_FUSED_STORE", "1") != "0")
         self._num_kv_heads_hint = getattr(getattr(model_runner, "kvcache", None), "head_num", None)
+        # planned decode: lay the plan out for at least this many tokens (a captured decode step needs every kernel
+        # argument - the plan's layout among them - to stay the same while the batch grows)
+        self.decode_capacity_hint = 0
 
     # ---- metadata -------------------------------------------------------------------------------
     def _ws(self, nbytes: int, device) -> Optional[torch.Tensor]:
@@ -119,7 +122,7 @@ class MI355AttnBackend:
         if self.decode_mode == "planned":
             Hq, Hkv, D = layer.num_heads, layer.num_kv_heads, layer.head_dim
             if md.plan is None:                        # first layer of this forward: lay the token stream out once
-                cap = self._plan_key[1]
+                cap = max(self._plan_key[1], int(self.decode_capacity_hint))
                 md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
                                           self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
                 self._plan_buf = md.plan.buf

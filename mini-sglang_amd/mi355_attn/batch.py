@@ -223,11 +223,7 @@ class Batch:
         self.input_ids = self.output_ids
         self.output_ids = None
         if getattr(self.kvcache, "ring", None) is not None:
-            # device free list: the host only counts the pages this step takes (and moves its mirror of the FIFO)
-            lens = np.asarray(self.seq_lens_host, dtype=np.int64)
-            if not self.kvcache.take_on_device(int((lens % self.page_size == 0).sum())):
-                raise RuntimeError("KV pool exhausted during decode (call check_decode_mem / retract_decode first)")
-            self.seq_lens_host = (lens + 1).tolist()
+            self.advance_host_for_decode()
             self.seq_lens, self.positions, self.out_cache_loc = ops.decode_prepare_ring(
                 self.page_manager.page_table, self.page_table_ids, self.seq_lens, self.kvcache.ring, self.page_size)
         else:
@@ -236,6 +232,17 @@ class Batch:
                 self.page_manager.page_table, self.page_table_ids, self.seq_lens, _h2d(new_pages, self.device),
                 self.page_size)
         self.cu_q = self.row_of_token = None
+
+    def advance_host_for_decode(self) -> None:
+        """Host half of a decode step with the device free list: count the pages the step takes, move the host mirror
+        of the FIFO, bump the mirrored lengths.  (The device half is m355_decode_prepare_ring - eager or replayed
+        from a captured graph.)"""
+        if self.seq_lens_host is None:
+            self.seq_lens_host = [int(x) for x in self.seq_lens.tolist()]
+        lens = np.asarray(self.seq_lens_host, dtype=np.int64)
+        if not self.kvcache.take_on_device(int((lens % self.page_size == 0).sum())):
+            raise RuntimeError("KV pool exhausted during decode (call check_decode_mem / retract_decode first)")
+        self.seq_lens_host = (lens + 1).tolist()
 
     # ---- bookkeeping kept working (engine/batch.py:345-464)
     def filter_batch(self, keep_indices: Optional[List[int]] = None) -> None:

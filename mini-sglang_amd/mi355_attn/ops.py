@@ -134,16 +134,23 @@ class PageRing:
 
 
 def decode_prepare_ring(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: torch.Tensor, ring: PageRing,
-                        page_size: int):
+                        page_size: int, out=None):
     """decode_prepare with the page allocation done by the kernel from the device FIFO (m355_decode_prepare_ring):
-    no page ids cross PCIe.  Returns (new_seq_lens, positions, out_cache_loc)."""
+    no page ids cross PCIe.  Returns (new_seq_lens, positions, out_cache_loc); `out` = those three as caller-owned
+    int64 [B] buffers (new_seq_lens may be `seq_lens` itself: a captured step updates its lengths in place)."""
     lib = _lib.load()
     for n, t in (("page_table", page_table), ("rows", rows), ("seq_lens", seq_lens)):
         require_cuda(t, n)
     assert rows.dtype == torch.int64 and seq_lens.dtype == torch.int64
     assert seq_lens.is_contiguous() and rows.is_contiguous()
     B = seq_lens.numel()
-    trio = torch.empty((3, B), dtype=torch.int64, device=seq_lens.device)     # new seq_lens | positions | loc
+    if out is not None:
+        trio = out
+        for t in trio:
+            require_cuda(t, "out")
+            assert t.dtype == torch.int64 and t.numel() == B and t.is_contiguous()
+    else:
+        trio = torch.empty((3, B), dtype=torch.int64, device=seq_lens.device)     # new seq_lens | positions | loc
     check(lib.m355_decode_prepare_ring(page_table.data_ptr(), page_table.stride(0), rows.data_ptr(), seq_lens.data_ptr(),
                                        trio[0].data_ptr(), ring.ring.data_ptr(), ring.state.data_ptr(), ring.capacity,
                                        B, page_size, trio[1].data_ptr(), trio[2].data_ptr(), current_stream()),

@@ -72,3 +72,21 @@ def test_tp2_rehearsal_matches_tp1_first_tokens():
     assert two.returncode == 0 and "correctness: PASS" in two.stdout, two.stdout[-2000:] + two.stderr[-2000:]
     first = lambda out: [int(x) for x in re.findall(r"Prompt \d+ =+ \[(\d+)", out)]
     assert len(first(one.stdout)) == 3 and first(one.stdout) == first(two.stdout)
+
+
+@pytest.mark.parametrize("model,ps", [("tiny", 16), ("tiny128", 4)])
+def test_graphed_decode_equals_the_eager_loop(model, ps):
+    """One decode step captured as a HIP graph (device free list, in-place metadata, fixed plan layout) and replayed
+    must generate exactly the eager loop's tokens, across page boundaries."""
+    import bench_one_batch as bob
+    from harness.llama_shell import SHAPES, HarnessRunner
+    shape = SHAPES[model]
+    B, L, out_len = 4, 40, 3 * ps + 4 if ps <= 4 else 24
+    runner = HarnessRunner(shape, ps, max_total_tokens=B * (L + out_len + 2 * ps) + 64 * ps, max_reqs=B, context_len=L + out_len + ps,
+                           device="cuda")
+    prompts = [p[: L - 3 * i] for i, p in enumerate(bob.synth_prompts(B, L, shape.vocab, seed=5))]
+    _, eager = bob.three_phase(runner, prompts, 0, out_len)
+    bob.reset_pools(runner)
+    _, graphed = bob.three_phase(runner, prompts, 0, out_len, graph=True)
+    assert torch.equal(eager, graphed)
+    assert runner.kvcache.ring.snapshot() == runner.kvcache.free_pages
