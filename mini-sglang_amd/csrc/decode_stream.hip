@@ -42,37 +42,49 @@ __device__ __forceinline__ int upper_bound_minus1(const int32_t* cum, int n, int
 
 __device__ __forceinline__ int32_t pieces_of(int32_t a, int32_t e, int32_t R) { return e > a ? (e - 1) / R - a / R + 1 : 0; }
 
+constexpr int kCumLds = 4096;                       // requests whose cumulative lengths the plan kernels stage in LDS
+
 __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nwh,
                                                          int32_t r_min, int64_t cap, int32_t* __restrict__ plan,
                                                          PlanLayout L) {
-    __shared__ int32_t part[1024];
-    const int tid = threadIdx.x;
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t cum_s[kCumLds + 1];                // cum of the first kCumLds requests: the record loop's binary
+    __shared__ int32_t pb_s[kCumLds + 1];                 // searches and piece walks then stay out of global memory
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t* cum = plan + L.cum;
     int32_t* pbase = plan + L.pbase;
     const int per = (B + 1023) / 1024;
     const int lo = tid * per, hi = min(B, lo + per);
-    auto block_scan = [&](int32_t mine) -> int32_t {       // exclusive scan of one value per thread
-        part[tid] = mine;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const int32_t v = tid >= d ? part[tid - d] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
+    auto block_scan = [&](int32_t mine) -> int32_t {       // exclusive scan of one value per thread: 6 shuffles + 16 wave sums
+        int32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
         }
-        const int32_t excl = part[tid] - mine;
+        if (lane == 63) wsum[wv] = incl;
         __syncthreads();
-        return excl;
+        int32_t base = 0;
+        for (int k = 0; k < wv; ++k) base += wsum[k];
+        __syncthreads();
+        return base + incl - mine;
     };
+    const bool staged = B <= kCumLds;
     int32_t s = 0;
     for (int b = lo; b < hi; ++b) s += (int32_t)seq_lens[b];
     int32_t run = block_scan(s);
     // lengths are clamped so the stream never exceeds the slot slabs (a too-small capacity truncates, never overruns)
     const int32_t icap = (int32_t)cap;
-    for (int b = lo; b < hi; ++b) { cum[b] = run < icap ? run : icap; run += (int32_t)seq_lens[b]; }
-    if (tid == 1023) cum[B] = run < icap ? run : icap;     // the last thread's running sum is the grand total
+    for (int b = lo; b < hi; ++b) {
+        const int32_t c = run < icap ? run : icap;
+        cum[b] = c;
+        if (staged) cum_s[b] = c;
+        run += (int32_t)seq_lens[b];
+    }
+    if (tid == 1023) { const int32_t c = run < icap ? run : icap; cum[B] = c; if (staged) cum_s[B] = c; }   // the grand total
     __syncthreads();
-    const int32_t total = cum[B];
+    const int32_t* cu = staged ? cum_s : cum;
+    const int32_t total = cu[B];
     // one range per resident wave; when that would exceed kRMax tokens, k equal ranges per wave (k rounds of the
     // grid-stride loop) rather than kRMax-token ranges whose count is no multiple of the wave count
     const int32_t per_wave = (total + nwh - 1) / nwh;
@@ -83,29 +95,34 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
     if (tid == 0) { plan[0] = total; plan[1] = R; plan[2] = B; plan[3] = nwh; plan[4] = n_ranges; plan[5] = plan[6] = plan[7] = 0; }
     // partials per request -> pbase
     s = 0;
-    for (int b = lo; b < hi; ++b) s += pieces_of(cum[b], cum[b + 1], R);
+    for (int b = lo; b < hi; ++b) s += pieces_of(cu[b], cu[b + 1], R);
     run = block_scan(s);
-    for (int b = lo; b < hi; ++b) { pbase[b] = run; run += pieces_of(cum[b], cum[b + 1], R); }
-    if (tid == 1023) pbase[B] = run;
+    for (int b = lo; b < hi; ++b) {
+        pbase[b] = run;
+        if (staged) pb_s[b] = run;
+        run += pieces_of(cu[b], cu[b + 1], R);
+    }
+    if (tid == 1023) { pbase[B] = run; if (staged) pb_s[B] = run; }
     __syncthreads();
+    const int32_t* pb = staged ? pb_s : pbase;
     // range records
     for (int r = tid; r < L.max_ranges; r += 1024) {
         int32_t* rec = plan + L.rec + (int64_t)r * kRec;
         if (r >= n_ranges) { rec[0] = 0; rec[1] = 0; rec[2] = 0; rec[3] = 0; continue; }
         const int32_t g0 = r * R, g1 = min(total, g0 + R);
-        int b = upper_bound_minus1(cum, B, g0);
+        int b = upper_bound_minus1(cu, B, g0);
         rec[0] = g1 - g0; rec[2] = b; rec[3] = g0;
         int np = 0;
         int32_t endmask = 0;                                 // bit k: piece k ends its request (holds the newest token)
-        for (; b < B && cum[b] < g1; ++b) {
-            const int32_t cs = cum[b], ce = cum[b + 1];
+        for (; b < B && cu[b] < g1; ++b) {
+            const int32_t cs = cu[b], ce = cu[b + 1];
             const int32_t lo2 = max(cs, g0), hi2 = min(ce, g1);
             if (hi2 <= lo2) continue;                        // empty request
             if (np == kMaxPieces) { np = -1; break; }        // too many: the attention kernel scans cum itself
             rec[4 + np * 4 + 0] = b;
             rec[4 + np * 4 + 1] = lo2 - g0;
             rec[4 + np * 4 + 2] = hi2 - lo2;
-            rec[4 + np * 4 + 3] = (lo2 == cs && hi2 == ce) ? -1 : pbase[b] + (r - cs / R);
+            rec[4 + np * 4 + 3] = (lo2 == cs && hi2 == ce) ? -1 : pb[b] + (r - cs / R);
             if (hi2 == ce) endmask |= 1 << np;
             ++np;
         }
@@ -117,8 +134,14 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
 __global__ __launch_bounds__(256) void plan_slots_kernel(const int32_t* __restrict__ page_table, int64_t pt_stride,
                                                          const int64_t* __restrict__ rows, int32_t B, int32_t ps,
                                                          int32_t* __restrict__ plan, PlanLayout L) {
+    __shared__ int32_t cum_s[kCumLds + 1];
     const int32_t total = plan[0], R = plan[1];
     const int32_t* cum = plan + L.cum;
+    if (B <= kCumLds) {                                      // the per-token binary search then runs in LDS
+        for (int i = threadIdx.x; i <= B; i += blockDim.x) cum_s[i] = cum[i];
+        __syncthreads();
+        cum = cum_s;
+    }
     int32_t* slabs = plan + L.slots;
     for (int32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
         const int b = upper_bound_minus1(cum, B, g);
