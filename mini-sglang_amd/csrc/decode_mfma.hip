@@ -267,19 +267,6 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
             *reinterpret_cast<u32x4*>(qsp + i * 16) =
                 *reinterpret_cast<const u32x4*>(p.q + (int64_t)pc[(p0 + k) * 4] * p.q_stride + (int64_t)h * G * D + c * 8);
         }
-        if (fused) {                                     // ... and the new rows of this head -> their pool slots
-            for (int k = 0; k < np; ++k) {
-                if (!((endmask >> (p0 + k)) & 1u)) continue;
-                if (lane < 2 * M::C) {
-                    const int c = lane % M::C;
-                    const int64_t bq = pc[(p0 + k) * 4];
-                    const int64_t slot = slots[pc[(p0 + k) * 4 + 1] + pc[(p0 + k) * 4 + 2] - 1];
-                    const uint16_t* src = (lane < M::C ? p.k_new + bq * p.kn_stride : p.v_new + bq * p.vn_stride) + h * D + c * 8;
-                    uint16_t* dst = const_cast<uint16_t*>(lane < M::C ? p.k_pool : p.v_pool) + slot * p.row_elems + h * D + c * 8;
-                    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
-                }
-            }
-        }
         __syncthreads();
         sstamp<STAMP>(p, 3);
         while (ck < np) {
@@ -289,6 +276,22 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                     if (lk < np) issue((j + R - 1) % R);
                     wait_tiles_younger<R - 1, 2 * M::NI>(issued - consumed - 1);
                     consume(j);
+                }
+            }
+        }
+        if (fused) {
+            // the new rows of this head -> their pool slots, AFTER the stream: a store in front of it sits in the
+            // same vmcnt queue as the DMA stages, and the first counted wait behind it would also wait for its
+            // write acknowledge
+            for (int k = 0; k < np; ++k) {
+                if (!((endmask >> (p0 + k)) & 1u)) continue;
+                if (lane < 2 * M::C) {
+                    const int c = lane % M::C;
+                    const int64_t bq = pc[(p0 + k) * 4];
+                    const int64_t slot = slots[pc[(p0 + k) * 4 + 1] + pc[(p0 + k) * 4 + 2] - 1];
+                    const uint16_t* src = (lane < M::C ? p.k_new + bq * p.kn_stride : p.v_new + bq * p.vn_stride) + h * D + c * 8;
+                    uint16_t* dst = const_cast<uint16_t*>(lane < M::C ? p.k_pool : p.v_pool) + slot * p.row_elems + h * D + c * 8;
+                    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
                 }
             }
         }
