@@ -164,14 +164,17 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
 #pragma unroll
             for (int dt = 0; dt < M::DT; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         };
-        auto end_piece = [&]() {
-            float a, b;
-            lane_pair<16>(l_run, a, b);
-            float l = a + b;
-            lane_pair<32>(l, a, b);
-            l = a + b;
-            const int bq = pc[(p0 + ck) * 4 + 0];
-            const int pidx = pc[(p0 + ck) * 4 + 3];
+        // A finished piece's results wait in registers until the NEXT stage has been waited for: stored at once they
+        // would sit in front of that stage in the vmcnt queue and the counted wait would include their write acknowledge.
+        bool pend = false;
+        int pend_bq = 0, pend_pidx = 0;
+        float pend_m = 0.f, pend_l = 0.f;
+        f32x4 pend_O[M::DT];
+        auto flush_piece = [&]() {
+            pend = false;
+            const int bq = pend_bq, pidx = pend_pidx;
+            const float l = pend_l, m_run = pend_m;
+            const f32x4 (&O)[M::DT] = pend_O;
             if (n < G) {
                 if (pidx < 0) {                          // the piece is the whole request: final output
                     const float inv = 1.f / l;
@@ -189,6 +192,20 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                     if (kg == 0) { p.ws_ml[idx * 2] = m_run; p.ws_ml[idx * 2 + 1] = l; }
                 }
             }
+        };
+        auto end_piece = [&]() {
+            if (pend) flush_piece();                     // (two piece ends without a wait in between: tiny pieces)
+            float a, b;
+            lane_pair<16>(l_run, a, b);
+            float l = a + b;
+            lane_pair<32>(l, a, b);
+            pend_l = a + b;
+            pend_m = m_run;
+            pend_bq = pc[(p0 + ck) * 4 + 0];
+            pend_pidx = pc[(p0 + ck) * 4 + 3];
+#pragma unroll
+            for (int dt = 0; dt < M::DT; ++dt) pend_O[dt] = O[dt];
+            pend = true;
         };
         auto consume = [&](const int RS) {
             const uint8_t* st = ringp + RS * M::STAGEB;
@@ -275,10 +292,12 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                 if (ck < np) {
                     if (lk < np) issue((j + R - 1) % R);
                     wait_tiles_younger<R - 1, 2 * M::NI>(issued - consumed - 1);
+                    if (pend) flush_piece();
                     consume(j);
                 }
             }
         }
+        if (pend) flush_piece();
         if (fused) {
             // the new rows of this head -> their pool slots, AFTER the stream: a store in front of it sits in the
             // same vmcnt queue as the DMA stages, and the first counted wait behind it would also wait for its
