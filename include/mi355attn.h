@@ -163,7 +163,8 @@ int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const vo
  * 0 .. prefix_lens[b] + j (its own K/V included - they are read back from the pool).
  * cu_q: int32 [B+1] exclusive prefix sum of (seq_lens - prefix_lens); T = cu_q[B];
  * max_extend_len >= max(seq_lens - prefix_lens) and max_seq_len_hint >= max(seq_lens) size the grid.
- * workspace: fp32 scratch of m355_prefill_workspace_bytes(...) bytes (may be NULL when that is 0). */
+ * workspace: fp32 scratch of m355_prefill_workspace_bytes(...) bytes (may be NULL when that is 0; non-zero when the
+ * launch is cut into KV splits - few query rows over long histories - whose partials a second kernel merges). */
 int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D, int32_t max_seq_len_hint);
 int m355_prefill_attn(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
                       const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,

@@ -38,6 +38,8 @@ struct PrefillParams {
     int32_t B, Hq, Hkv, ps, ps_shift, tiles_max;
     float scale_log2;
     unsigned long long* stamps;                       // dev-only: per-wave phase cycle sums (STAMP builds)
+    float* ws;                                        // split-KV partials [T*Hq rows][splits][D + 4: O, m, l, pad] (splits > 1)
+    int32_t splits;                                   // KV splits per row block (blockIdx.y)
 };
 static unsigned long long* g_prefill_stamps = nullptr;
 
@@ -303,7 +305,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     const int j_last_wg = min(E - 1, (ROWS_WG * tb + ROWS_WG - 1) / G);
     const int kv_end_wg = P + j_last_wg + 1;                       // tokens any row of the workgroup attends
     const int n_tiles = (kv_end_wg + 31) >> 5;
-    const int n_pairs = (n_tiles + 1) >> 1;
+    const int n_pairs_all = (n_tiles + 1) >> 1;
+    // split-KV (few row blocks, long KV): this workgroup walks pairs [p_begin, n_pairs) only and leaves fp32 partials
+    const int p_begin = p.splits > 1 ? (int)((int64_t)n_pairs_all * blockIdx.y / p.splits) : 0;
+    const int n_pairs = p.splits > 1 ? (int)((int64_t)n_pairs_all * (blockIdx.y + 1) / p.splits) : n_pairs_all;   // exclusive end
 
     // ---- this wave's row tile: the lane's row, its limit, Q^T fragments
     const int t = tb * NW + wid;                                   // row tile index inside the request
@@ -328,7 +333,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
     }
-    float m_run = kNegBig, l_run = 0.f;
+    // The running max starts at a floor far below any real score but far ABOVE a masked one (kNegBig * scale): a row
+    // whose first pair is entirely masked - possible in a later KV split - then keeps the floor and gets p = 0 for
+    // every masked entry, instead of "max = the mask value" and p = 2^(rounding noise of 1e29).
+    constexpr float kRunFloor = -1.0e20f;
+    float m_run = kRunFloor, l_run = 0.f;
 
     // ---- DMA duty of this wave: instruction ids wid, wid + 4, ... of the tile's 2*NI (K first, then V)
     const int drow = l / W::C, dch = l % W::C;
@@ -360,6 +369,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     constexpr int HP = IPW / 2;
     auto pair_slots = [&](int pair, int32_t (&sl)[IPW]) {
         pair = pair < n_pairs ? pair : n_pairs - 1;
+        pair = pair > p_begin ? pair : p_begin;            // (an empty split: clamped to a pair that exists)
+        pair = pair < n_pairs_all ? pair : n_pairs_all - 1;
         if ((2 * pair) / (kSlotWin / 32) != cur_win) fill_slots((2 * pair) / (kSlotWin / 32));   // workgroup-uniform
 #pragma unroll
         for (int x = 0; x < IPW; ++x) {
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     wait_vmcnt<0>();                                               // q fragments are in: the DMA count starts clean
 #pragma unroll
     for (int j = 0; j < NP - 1; ++j)
-        issue_pair(j, 2 * j);
+        issue_pair(p_begin + j, 2 * j);
 
     // K fragment s of the tile in buffer `buf` (ds_read_b128) and V^T fragment f = 2*dt + ks (two transposed reads:
     // token rows 16 ks + 4 hh + q and + 8; the swizzle only depends on the row modulo 8)
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         l_run = fmaf(l_run, alpha, sum);
         stamp(4);
     };
-    for (int k0 = 0; k0 < n_pairs; k0 += NP) {
+    for (int k0 = p_begin; k0 < n_pairs; k0 += NP) {
         pair_step(k0, IntC<0>{});
         if (k0 + 1 < n_pairs) pair_step(k0 + 1, IntC<1>{});
         if constexpr (NP > 2) { if (k0 + 2 < n_pairs) pair_step(k0 + 2, IntC<2>{}); }
@@ -561,6 +572,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     }
     float la, lb;
     lane_pair<32>(l_run, la, lb);
+    if (p.splits > 1) {                                            // unnormalised partial of this split: O^T, m, l
+        if (valid) {
+            float* wo = p.ws + (((qrow0 + jrow) * p.Hq + (h * G + grow)) * p.splits + blockIdx.y) * (D + 4);
+#pragma unroll
+            for (int dt = 0; dt < W::DT; ++dt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *reinterpret_cast<f32x4*>(wo + 32 * dt + 8 * q4 + 4 * hh) =
+                        f32x4{o[dt][4 * q4 + 0], o[dt][4 * q4 + 1], o[dt][4 * q4 + 2], o[dt][4 * q4 + 3]};
+            if (hh == 0) { wo[D] = m_run; wo[D + 1] = la + lb; }
+        }
+        return;
+    }
     const float inv = 1.f / (la + lb);
     if (valid) {
         uint16_t* op = p.out + (qrow0 + jrow) * p.o_stride + (int64_t)(h * G + grow) * D + 4 * hh;
@@ -588,6 +612,49 @@ static int prefill_mode() {      // tuning / cross-check hook: 1 = row-parallel 
     return v;
 }
 
+// KV splits per row block: only when the whole launch has too few row blocks (T*Hq/128 of them, all requests and
+// heads) to occupy the chip's 512 workgroup slots and the KV is long - a short new turn over a long cached history.
+// Splits bring the workgroup count to about 512, each keeping at least 512 tokens; the partials stay small
+// (splits * T * Hq <= 2^16 rows of D + 4 floats).  The same rule sizes the workspace.  (With 270 blocks - every CU
+// already busy - 4 splits measured no gain: 260 us either way; with 15 blocks 8 splits gave 319 -> 60 us.)
+static int prefill_splits(int64_t T, int32_t Hq, int32_t max_seq_len) {
+    static const int forced = [] { const char* e = getenv("M355_PREFILL_SPLITS"); return e ? atoi(e) : 0; }();   // A/B hook: 1 = never
+    if (forced == 1) return 1;
+    const int64_t blocks = (T * Hq + 127) / 128;
+    int s = (int)(512 / (blocks > 0 ? blocks : 1));
+    if (s > 32) s = 32;
+    while (s > 1 && max_seq_len / s < 512) --s;
+    return s < 1 ? 1 : s;
+}
+
+// out[row, head, :] = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M): 32 lanes per (row, head), 4 floats each (D = 128)
+// or 16 lanes (D = 64)
+template <int D>
+__global__ __launch_bounds__(256) void prefill_merge_kernel(const float* __restrict__ ws, uint16_t* __restrict__ out,
+                                                            int64_t o_stride, int64_t n_items, int32_t Hq, int32_t S) {
+    constexpr int LPI = D / 4;                                      // lanes per item
+    const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPI;
+    const int li = threadIdx.x % LPI;
+    if (item >= n_items) return;
+    const float* base = ws + item * S * (D + 4);
+    float M = kNegBig;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, base[s * (D + 4) + D]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float w = exp2_fast(base[s * (D + 4) + D] - M);
+        den = fmaf(w, base[s * (D + 4) + D + 1], den);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(base + s * (D + 4) + 4 * li);
+        acc += o * w;
+    }
+    const float inv = 1.f / den;
+    const int64_t row = item / Hq, head = item % Hq;
+    uint2 w;
+    w.x = pack_bf16(acc[0] * inv, acc[1] * inv);
+    w.y = pack_bf16(acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<uint2*>(out + row * o_stride + head * D + 4 * li) = w;
+}
+
 static int prefill_wg_cfg() {    // tuning hook: M355_PREFILL_WG = 10*waves + ring tiles/4, e.g. 41 (4 waves, 4 tiles), 42, 82
     static int v = [] { const char* e = getenv("M355_PREFILL_WG"); return e ? atoi(e) : 0; }();
     return v;
@@ -596,7 +663,7 @@ static int prefill_wg_cfg() {    // tuning hook: M355_PREFILL_WG = 10*waves + ri
 template <int D, int G, int NW, int NBUF>
 static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream_t st) {
     p.tiles_max = (max_extend_len * G + 32 * NW - 1) / (32 * NW);
-    const dim3 grid((unsigned)((int64_t)p.B * p.Hkv * p.tiles_max)), block(64 * NW);
+    const dim3 grid((unsigned)((int64_t)p.B * p.Hkv * p.tiles_max), (unsigned)p.splits), block(64 * NW);
     const size_t lds = NBUF * WgCfg<D>::BUFB + kSlotWin * 4;   // K tiles, V tiles, slot window
     static bool attr_done = [] {
         (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, NW, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -647,7 +714,11 @@ extern "C" int m355dbg_set_prefill_stamp_buffer(void* dev_ptr) {   // dev-only (
 
 extern "C" int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D, int32_t max_seq_len_hint) {
     if (T <= 0 || Hq <= 0 || D <= 0 || max_seq_len_hint <= 0) return 0;
-    if (prefill_mode() != 1) return 0;                   // the MFMA path keeps everything on chip
+    if (prefill_mode() == 0) {                            // split-KV partials of the workgroup kernel (few rows, long KV)
+        const int sp = prefill_splits(T, Hq, max_seq_len_hint);
+        return sp > 1 ? (int64_t)T * Hq * sp * (D + 4) * (int64_t)sizeof(float) : 0;
+    }
+    if (prefill_mode() != 1) return 0;
     const int64_t splits = (max_seq_len_hint + kRowsMaxChunk - 1) / kRowsMaxChunk;
     if (splits <= 1) return 0;
     return (int64_t)T * Hq * splits * (D + 2) * (int64_t)sizeof(float);
@@ -683,10 +754,25 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     p.tiles_max = (max_extend_len * G + 31) / 32;
     p.scale_log2 = scale * kLog2e;
     p.stamps = nullptr;
+    p.ws = nullptr;
+    p.splits = 1;
+    if (prefill_mode() == 0) {
+        p.splits = prefill_splits(T, Hq, max_seq_len_hint);
+        if (p.splits > 1) {
+            const int64_t need = (int64_t)T * Hq * p.splits * (D + 4) * (int64_t)sizeof(float);
+            if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return M355_ERR_WORKSPACE;
+            p.ws = (float*)workspace;
+        }
+    }
     if ((int64_t)B * Hkv * p.tiles_max > 0x7fffffffLL) return M355_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define M355_CASE(DD, GG) if (D == DD && G == GG) { \
         if (prefill_mode() == 2) launch_prefill<DD, GG>(p, st); else launch_prefill_wg<DD, GG>(p, max_extend_len, st); \
+        if (p.splits > 1) { \
+            const int64_t items = (int64_t)T * Hq; \
+            hipLaunchKernelGGL((prefill_merge_kernel<DD>), dim3((unsigned)((items * (DD / 4) + 255) / 256)), dim3(256), 0, st, \
+                               p.ws, p.out, p.o_stride, items, Hq, p.splits); \
+        } \
         return check_launch(); }
     M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
     M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)

@@ -421,6 +421,32 @@ def test_prefill_long_sequences_and_late_spike(Hq, Hkv, D, ps):
     assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL), float((o.float() - ref).abs().max())
 
 
+@pytest.mark.parametrize("Hq,Hkv,D,ps", [(32, 8, 128, 16), (32, 8, 64, 16), (8, 1, 128, 1), (16, 4, 128, 12)])
+def test_prefill_short_turns_over_long_histories(Hq, Hkv, D, ps):
+    """A few new tokens per request over thousands of cached ones (RadixCache hit of a long chat history): few row
+    blocks, long KV - the launch is cut into KV splits whose fp32 partials a second kernel merges.  Includes a request
+    with no prefix, one whose extend is a single token, and split counts that leave some splits empty."""
+    m, ops = _mods()
+    pre = [4096, 6000, 0, 2048, 515]
+    ext = [40, 1, 70, 17, 130]
+    pre = [p // ps * ps for p in pre]
+    seq = [p + e for p, e in zip(pre, ext)]
+    B = len(seq)
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, seq, seed=D + ps)
+    T = sum(ext)
+    assert ops.prefill_workspace_bytes(T, Hq, D, max(seq)) > 0          # this shape is split
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn((T, Hq * D), generator=g).to(torch.bfloat16).to(DEV)
+    dk, dv = kp.to(DEV), vp.to(DEV)
+    dt, dr = torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV)
+    ref = _gpu_prefill_reference(q, dk, dv, dt, rows.tolist(), seq, pre, ps, Hq)
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(ext)]), dtype=torch.int32, device=DEV)
+    o = ops.prefill_attn(q, dk, dv, dt, dr, torch.tensor(seq, device=DEV), torch.tensor(pre, device=DEV), cu, ps, Hq,
+                         max(ext), max(seq))
+    assert torch.isfinite(o.float()).all()
+    assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL), float((o.float() - ref).abs().max())
+
+
 def test_decode_cfg2_full_size_properties():
     """BASELINE.json configs[1] at full size (1B heads, B=64 ragged 146..2046, ps=16, shuffled pages):
     the result must not depend on the chunking, and must match a torch fp32 computation on the GPU."""
