@@ -219,23 +219,31 @@ def main():
     traffic = pmc_traffic(planned) if tp == 1 and not (args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1) else None
 
     # ---- the layer's one collective, outside the path: o_proj's row-parallel all-reduce, timed on its own
-    allreduce = None
-    if tp > 1:
+    def time_allreduce(t, reps):
         for _ in range(3):
-            all_reduce_rows(red)
+            all_reduce_rows(t)
         fence()
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
-        for _ in range(50):
-            all_reduce_rows(red)
+        for _ in range(reps):
+            all_reduce_rows(t)
         a1.record()
         torch.cuda.synchronize()
-        us = torch.tensor([a0.elapsed_time(a1) * 1e3 / 50], device=dev, dtype=torch.float64)
+        us = torch.tensor([a0.elapsed_time(a1) * 1e3 / reps], device=dev, dtype=torch.float64)
         dist.all_reduce(us, op=dist.ReduceOp.MAX)
-        nbytes = red.numel() * red.element_size()
-        allreduce = {"tensor": f"[{B}, {hidden}] bf16", "bytes": nbytes, "us": round(float(us.item()), 2),
-                     "algbw_GBps": round(nbytes / float(us.item()) / 1e3, 1),
-                     "busbw_GBps": round(nbytes / float(us.item()) / 1e3 * 2 * (tp - 1) / tp, 1)}
+        nbytes = t.numel() * t.element_size()
+        return {"tensor": f"{list(t.shape)} bf16", "bytes": nbytes, "us": round(float(us.item()), 2),
+                "algbw_GBps": round(nbytes / float(us.item()) / 1e3, 1),
+                "busbw_GBps": round(nbytes / float(us.item()) / 1e3 * 2 * (tp - 1) / tp, 1)}
+
+    allreduce = allreduce_cfg4 = None
+    if tp > 1:
+        allreduce = time_allreduce(red, 3 if rehearse else 50)          # (gloo: ~1 s per bf16 all-reduce)
+        # SURVEY 8d cfg4 (Llama-3-8B, hidden 4096): the decode-size and the prefill-size message of that model
+        if not rehearse:                               # (gloo reduces 40 MB of bf16 on the host: minutes, and meaningless)
+            allreduce_cfg4 = {
+                "decode_B64": time_allreduce(torch.zeros((64, 4096), dtype=torch.bfloat16, device=dev), 50),
+                "prefill_T4863": time_allreduce(torch.zeros((4863, 4096), dtype=torch.bfloat16, device=dev), 10)}
 
     cpu = None
     if rank == 0 and tp == 1 and not args.no_cpu_baseline:
@@ -263,6 +271,7 @@ def main():
         }
         if allreduce is not None:
             line["allreduce_o_proj"] = allreduce
+            line["allreduce_o_proj_llama3_8b"] = allreduce_cfg4
         print(json.dumps(line), flush=True)
     if tp > 1:
         dist.destroy_process_group()
