@@ -35,7 +35,9 @@ int64_t m355r_last_match(void *tree, int32_t *out_pages, int64_t cap);
 int64_t m355r_insert(void *tree, const int64_t *key, int64_t n_tokens, const int32_t *pages, int64_t n_pages);
 
 /* inc_lock_ref / dec_lock_ref (radix_cache.py:223-252) from `node` up to the root; return the change of the
- * evictable size in tokens (<= 0 for inc, >= 0 for dec). */
+ * evictable size in tokens (<= 0 for inc, >= 0 for dec).  A handle names its node until that node is evicted or the
+ * tree is reset; a handle whose node is gone is ignored (returns 0) - lock a matched node before anything that can
+ * evict, as the reference's callers do (engine/batch.py:128-150). */
 int64_t m355r_inc_lock_ref(void *tree, int64_t node);
 int64_t m355r_dec_lock_ref(void *tree, int64_t node);
 

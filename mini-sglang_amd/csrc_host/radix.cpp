@@ -7,6 +7,7 @@
 #include <cstring>
 #include <queue>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -36,11 +37,12 @@ struct Tree {
     uint64_t clock = 0;
     int64_t evictable = 0, protected_ = 0, nodes = 0;
     std::vector<int32_t> last_match;                       // pages of the latest match_prefix (m355r_last_match)
+    std::unordered_set<const Node*> live;                  // handles that still name a node of this tree
 
     explicit Tree(int32_t page_size) : ps(page_size) { reset(); }
     ~Tree() { destroy(root); }
 
-    Node* make() { Node* n = new Node(); n->stamp = ++clock; ++nodes; return n; }   // a new node is stamped (TreeNode.__init__)
+    Node* make() { Node* n = new Node(); n->stamp = ++clock; ++nodes; live.insert(n); return n; }   // a new node is stamped (TreeNode.__init__)
     void touch(Node* n) { n->stamp = ++clock; }
     void destroy(Node* n) {
         if (!n) return;
@@ -48,7 +50,7 @@ struct Tree {
         while (!st.empty()) {
             Node* x = st.back(); st.pop_back();
             for (auto& kv : x->children) st.push_back(kv.second);
-            delete x; --nodes;
+            live.erase(x); delete x; --nodes;
         }
     }
     void reset() {
@@ -165,7 +167,7 @@ int64_t m355r_insert(void* tp, const int64_t* key, int64_t n, const int32_t* pag
 int64_t m355r_inc_lock_ref(void* tp, int64_t h) {
     Tree* t = static_cast<Tree*>(tp);
     Node* node = (Node*)(intptr_t)h;
-    if (!t || !node) return 0;
+    if (!t || !node || !t->live.count(node)) return 0;       // a stale handle (its node was evicted) is ignored
     int64_t delta = 0;
     while (node != t->root) {
         if (node->lock_ref == 0) {
@@ -181,7 +183,7 @@ int64_t m355r_inc_lock_ref(void* tp, int64_t h) {
 int64_t m355r_dec_lock_ref(void* tp, int64_t h) {
     Tree* t = static_cast<Tree*>(tp);
     Node* node = (Node*)(intptr_t)h;
-    if (!t || !node) return 0;
+    if (!t || !node || !t->live.count(node)) return 0;       // a stale handle (its node was evicted) is ignored
     int64_t delta = 0;
     while (node != t->root) {
         if (node->lock_ref == 1) {
@@ -231,7 +233,7 @@ int64_t m355r_evict(void* tp, int64_t num_pages, int32_t* out, int64_t cap) {
         for (auto it = parent->children.begin(); it != parent->children.end(); ++it)
             if (it->second == x) { parent->children.erase(it); break; }
         t->evictable -= (int64_t)x->key.size();
-        delete x; --t->nodes;
+        t->live.erase(x); delete x; --t->nodes;
         if (parent->children.empty()) leaves.push(parent);
     }
     return done;
