@@ -36,6 +36,10 @@ enum {
     M355_ERR_LAUNCH = -4       /* hipGetLastError() after the launch was not hipSuccess         */
 };
 
+/* Element type of q / K / V / out.  Attention: bf16 everywhere; IEEE half (Llama-2-style fp16 checkpoints, the dtype
+ * the reference takes from the checkpoint, utils/model_config.py:40-42) through the default matrix-core kernels
+ * (m355_decode_attn_planned, m355_decode_store_attn_planned, m355_prefill_attn, m355_rope_kv_store); the plan-free
+ * m355_decode_attn is bf16 only.  f32 is accepted by m355_kv_store alone. */
 enum { M355_DTYPE_BF16 = 0, M355_DTYPE_F16 = 1, M355_DTYPE_F32 = 2 };
 
 int m355_version(void);

@@ -37,6 +37,41 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2v_t));
 }
 
+// ---- the 16-bit element type of q / K / V / out as a template flag: bf16 (F16 = false) or IEEE half (F16 = true).
+// Fragments travel as bf16x8 (a 128-bit container either way); only the matrix instruction, the f32 -> 16-bit
+// packing and the 16-bit -> f32 unpacking differ.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ uint32_t pack16(float lo, float hi) {        // round to nearest even, one v_cvt_pk_*
+    if constexpr (F16) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
+    } else {
+        return pack_bf16(lo, hi);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ float unpack16_lo(uint32_t w) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+    else return bf16_lo(w);
+}
+template <bool F16>
+__device__ __forceinline__ float unpack16_hi(uint32_t w) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+    else return bf16_hi(w);
+}
+
 // x + (x from the lane selected by a GFX9 DPP control); fuses into v_add_f32_dpp
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float x) {

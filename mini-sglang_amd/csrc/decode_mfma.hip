@@ -51,7 +51,7 @@ __host__ __device__ inline int mfma_lds_bytes(int D, int G, int R, int slots_cap
     return R * 64 * D * 2 + kQP * G * 2 * D + slots_cap * 4 + 64 * 4;
 }
 
-template <int D, int G, int R, bool STAMP>
+template <int D, int G, int R, bool STAMP, bool F16 = false>
 __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, const int slots_cap) {
     using M = MG<D>;
     static_assert(G <= 16, "q heads of a group sit in the 16 columns of one MFMA");
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                     uint16_t* op = p.out + (int64_t)bq * p.o_stride + (int64_t)(h * G + n) * D + 4 * kg;
 #pragma unroll
                     for (int dt = 0; dt < M::DT; ++dt) {
-                        uint32_t w0 = pack_bf16(O[dt][0] * inv, O[dt][1] * inv), w1 = pack_bf16(O[dt][2] * inv, O[dt][3] * inv);
+                        uint32_t w0 = pack16<F16>(O[dt][0] * inv, O[dt][1] * inv), w1 = pack16<F16>(O[dt][2] * inv, O[dt][3] * inv);
                         *reinterpret_cast<uint2*>(op + 16 * dt) = make_uint2(w0, w1);
                     }
                 } else {
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
             for (int s = 0; s < M::KS; ++s) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + (ka0 ^ (64 * s)));
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + 16 * M::ROWB + (ka0 ^ (64 * s)));
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[s], s1, 0, 0, 0);
+                s0 = mfma_16x16x32<F16>(a0, qf[s], s0);
+                s1 = mfma_16x16x32<F16>(a1, qf[s], s1);
             }
             const int rem = c_len - cit * 32;            // valid tokens of this stage
             if (rem < 32) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
 #pragma unroll
                 for (int dt = 0; dt < M::DT; ++dt) O[dt] *= alpha;
             }
-            const u32x4 pw = {pack_bf16(s0[0], s0[1]), pack_bf16(s0[2], s0[3]), pack_bf16(s1[0], s1[1]), pack_bf16(s1[2], s1[3])};
+            const u32x4 pw = {pack16<F16>(s0[0], s0[1]), pack16<F16>(s0[2], s0[3]), pack16<F16>(s1[0], s1[1]), pack16<F16>(s1[2], s1[3])};
             const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
             for (int dt = 0; dt < M::DT; ++dt) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)(va + 16 * M::ROWB));
                 const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), pf, O[dt], 0, 0, 0);
+                O[dt] = mfma_16x16x32<F16>(__builtin_bit_cast(bf16x8, av), pf, O[dt]);
             }
             ++consumed;
             ++cit;
@@ -423,12 +423,16 @@ int mfma_waves_per_cu(int Hkv, int D, int G, int64_t cap) {
 }
 
 template <int D, int G>
-static int launch_mfma(const StreamParams& p, int64_t cap, hipStream_t st, bool stamp) {
-    const int R = mfma_ring();
+static int launch_mfma(const StreamParams& p, int64_t cap, hipStream_t st, bool stamp, bool f16) {
+    const int R = f16 ? 2 : mfma_ring();               // (the tuning rings and the stamp build exist for bf16 only)
     const int slots_cap = mfma_slots_cap(p.nwh, cap);
     const int lds = mfma_lds_bytes(D, G, R, slots_cap);
     if (lds > 64 * 1024) return M355_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(p.Hkv * p.nwh)), block(64);
+    if (f16) {
+        hipLaunchKernelGGL((decode_mfma_kernel<D, G, 2, false, true>), grid, block, lds, st, p, slots_cap);
+        return M355_OK;
+    }
 #define M355_RING(RR) if (R == RR) { \
         if (stamp) hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, true>), grid, block, lds, st, p, slots_cap); \
         else hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, false>), grid, block, lds, st, p, slots_cap); }
@@ -437,8 +441,8 @@ static int launch_mfma(const StreamParams& p, int64_t cap, hipStream_t st, bool 
     return M355_OK;
 }
 
-int launch_stream_mfma(const StreamParams& p, int D, int G, int64_t cap, hipStream_t st, bool stamp) {
-#define M355_CASE(DD, GG) if (D == DD && G == GG) return launch_mfma<DD, GG>(p, cap, st, stamp);
+int launch_stream_mfma(const StreamParams& p, int D, int G, int64_t cap, hipStream_t st, bool stamp, bool f16) {
+#define M355_CASE(DD, GG) if (D == DD && G == GG) return launch_mfma<DD, GG>(p, cap, st, stamp, f16);
     M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
     M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)
 #undef M355_CASE

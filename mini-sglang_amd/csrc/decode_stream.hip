@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
 // NW waves per (request, q head): wave v combines partials v, v + NW, ...; the NW results meet in LDS.  NW = 1 for
 // batches whose requests are cut into a few pieces; long contexts in small batches (hundreds of pieces per request)
 // would otherwise walk them in one serial chain of memory latencies.
-template <int D, int NW>
+template <int D, int NW, bool F16 = false>
 __global__ __launch_bounds__(64 * NW) void stream_merge_kernel(const StreamParams p) {
     const int b = blockIdx.x / p.Hq;
     const int hq = blockIdx.x % p.Hq;
@@ -489,10 +489,9 @@ __global__ __launch_bounds__(64 * NW) void stream_merge_kernel(const StreamParam
     const float inv = 1.f / den;
     uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)hq * D + lane * E;
     if constexpr (E == 2) {
-        *reinterpret_cast<uint32_t*>(op) = pack_bf16(acc[0] * inv, acc[1] * inv);
+        *reinterpret_cast<uint32_t*>(op) = pack16<F16>(acc[0] * inv, acc[1] * inv);
     } else {
-        const __bf16 bb = (__bf16)(acc[0] * inv);
-        *op = __builtin_bit_cast(uint16_t, bb);
+        *op = (uint16_t)(pack16<F16>(acc[0] * inv, 0.f) & 0xffffu);
     }
 }
 
@@ -585,13 +584,13 @@ extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, in
 }
 
 // waves per (request, q head) of the merge: about one per 8 expected pieces of a request (ranges per head / requests)
-template <int D>
+template <int D, bool F16 = false>
 static void launch_merge(const StreamParams& p, hipStream_t st) {
     const int per_req = p.nwh / (p.B > 0 ? p.B : 1);
     const dim3 grid((unsigned)(p.B * p.Hq));
-    if (per_req >= 64) hipLaunchKernelGGL((stream_merge_kernel<D, 16>), grid, dim3(1024), 0, st, p);
-    else if (per_req >= 16) hipLaunchKernelGGL((stream_merge_kernel<D, 4>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((stream_merge_kernel<D, 1>), grid, dim3(64), 0, st, p);
+    if (per_req >= 64) hipLaunchKernelGGL((stream_merge_kernel<D, 16, F16>), grid, dim3(1024), 0, st, p);
+    else if (per_req >= 16) hipLaunchKernelGGL((stream_merge_kernel<D, 4, F16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((stream_merge_kernel<D, 1, F16>), grid, dim3(64), 0, st, p);
 }
 
 template <int D, int G>
@@ -617,7 +616,8 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     if (B == 0) return M355_OK;
     if (!q || !k_pool || !v_pool || !plan || !out || B < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || token_capacity <= 0)
         return M355_ERR_INVALID_ARG;
-    if (dtype != M355_DTYPE_BF16) return M355_ERR_UNSUPPORTED;
+    const bool f16 = dtype == M355_DTYPE_F16;          // IEEE half: the matrix-core kernel only
+    if (dtype != M355_DTYPE_BF16 && !(f16 && use_mfma())) return M355_ERR_UNSUPPORTED;
     if (D != 64 && D != 128) return M355_ERR_UNSUPPORTED;
     const int G = Hq / Hkv;
     if (G != 1 && G != 2 && G != 4 && G != 8) return M355_ERR_UNSUPPORTED;
@@ -644,9 +644,10 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     hipStream_t st = (hipStream_t)stream;
     if (k_new && !use_mfma()) return M355_ERR_UNSUPPORTED;   // the fused store lives in the MFMA kernel only
     if (use_mfma()) {
-        const int rc = launch_stream_mfma(p, D, G, token_capacity, st, getenv("M355_STREAM_STAMP") != nullptr);
+        const int rc = launch_stream_mfma(p, D, G, token_capacity, st, getenv("M355_STREAM_STAMP") != nullptr, f16);
         if (rc != M355_OK) return rc;
-        if (D == 64) launch_merge<64>(p, st); else launch_merge<128>(p, st);
+        if (f16) { if (D == 64) launch_merge<64, true>(p, st); else launch_merge<128, true>(p, st); }
+        else { if (D == 64) launch_merge<64>(p, st); else launch_merge<128>(p, st); }
         return check_launch();
     }
 #define M355_CASE(DD, GG) if (D == DD && G == GG) { launch_stream<DD, GG>(p, st); return check_launch(); }

@@ -40,6 +40,7 @@ struct PrefillParams {
     unsigned long long* stamps;                       // dev-only: per-wave phase cycle sums (STAMP builds)
     float* ws;                                        // split-KV partials [T*Hq rows][splits][D + 4: O, m, l, pad] (splits > 1)
     int32_t splits;                                   // KV splits per row block (blockIdx.y)
+    int32_t f16;                                      // elements are IEEE half instead of bf16
 };
 static unsigned long long* g_prefill_stamps = nullptr;
 
@@ -262,7 +263,7 @@ constexpr int kPrio = M355_PREFILL_PRIO;          // s_setprio 1 around the MFMA
 constexpr float kLazy = 8.f;                          // log2 units
 constexpr int kSlotWin = 1024;                        // tokens whose pool slots are staged in LDS at a time
 
-template <int D, int G, int NW, int NBUF, bool POW2, bool STAMP = false>
+template <int D, int G, int NW, int NBUF, bool POW2, bool STAMP = false, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(const PrefillParams p) {
     using W = WgCfg<D>;
     constexpr int NT = 64 * NW;                       // threads
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 w;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) w[x] = pack_bf16(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
+            for (int x = 0; x < 4; ++x) w[x] = pack16<F16>(s[8 * ks + 2 * x], s[8 * ks + 2 * x + 1]);
             pf[ks] = __builtin_bit_cast(bf16x8, w);
         }
         return sum;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {                          // S_a^T; tile b's K fragments fill in behind
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], qf[s], sa, 0, 0, 0);
+            sa = mfma_32x32x16<F16>(fa[s], qf[s], sa);
             fb[s] = rdk(2 * pb + 1, s);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {                          // S_b^T; tile a's V^T fragments take tile a's K registers
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], qf[s], sb, 0, 0, 0);
+            sb = mfma_32x32x16<F16>(fb[s], qf[s], sb);
             fa[s] = rdv(2 * pb, s);
         }
         if (kPrio) __builtin_amdgcn_s_setprio(0);
@@ -541,13 +542,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         if (kPrio == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) {                          // O^T += V_a^T P_a^T; tile b's V^T fragments fill in behind
-            o[s >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], pa[s & 1], o[s >> 1], 0, 0, 0);
+            o[s >> 1] = mfma_32x32x16<F16>(fa[s], pa[s & 1], o[s >> 1]);
             fb[s] = rdv(2 * pb + 1, s);
         }
         sum += exp_pack(sb, pbk);                                  // independent of the MFMAs above: interleaved with them
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < W::KS; ++s) o[s >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], pbk[s & 1], o[s >> 1], 0, 0, 0);
+        for (int s = 0; s < W::KS; ++s) o[s >> 1] = mfma_32x32x16<F16>(fb[s], pbk[s & 1], o[s >> 1]);
         if (kPrio == 2) __builtin_amdgcn_s_setprio(0);
         l_run = fmaf(l_run, alpha, sum);
         stamp(4);
@@ -593,8 +594,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 uint2 w;
-                w.x = pack_bf16(o[dt][4 * q4 + 0] * inv, o[dt][4 * q4 + 1] * inv);
-                w.y = pack_bf16(o[dt][4 * q4 + 2] * inv, o[dt][4 * q4 + 3] * inv);
+                w.x = pack16<F16>(o[dt][4 * q4 + 0] * inv, o[dt][4 * q4 + 1] * inv);
+                w.y = pack16<F16>(o[dt][4 * q4 + 2] * inv, o[dt][4 * q4 + 3] * inv);
                 *reinterpret_cast<uint2*>(op + 32 * dt + 8 * q4) = w;
             }
     }
@@ -629,7 +630,7 @@ static int prefill_splits(int64_t T, int32_t Hq, int32_t max_seq_len) {
 
 // out[row, head, :] = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M): 32 lanes per (row, head), 4 floats each (D = 128)
 // or 16 lanes (D = 64)
-template <int D>
+template <int D, bool F16 = false>
 __global__ __launch_bounds__(256) void prefill_merge_kernel(const float* __restrict__ ws, uint16_t* __restrict__ out,
                                                             int64_t o_stride, int64_t n_items, int32_t Hq, int32_t S) {
     constexpr int LPI = D / 4;                                      // lanes per item
@@ -650,8 +651,8 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(const float* __restr
     const float inv = 1.f / den;
     const int64_t row = item / Hq, head = item % Hq;
     uint2 w;
-    w.x = pack_bf16(acc[0] * inv, acc[1] * inv);
-    w.y = pack_bf16(acc[2] * inv, acc[3] * inv);
+    w.x = pack16<F16>(acc[0] * inv, acc[1] * inv);
+    w.y = pack16<F16>(acc[2] * inv, acc[3] * inv);
     *reinterpret_cast<uint2*>(out + row * o_stride + head * D + 4 * li) = w;
 }
 
@@ -678,13 +679,25 @@ static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream
             return;
         }
     }
+    if (p.f16) {                                                   // (default geometry only: NW = 4, 4 tile buffers)
+        if constexpr (NW == 4 && NBUF == 4) {
+            static bool attr16 = [] {
+                (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 4, 4, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 4, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                return true; }();
+            (void)attr16;
+            if (p.ps_shift >= 0) hipLaunchKernelGGL((prefill_wg_kernel<D, G, 4, 4, true, false, true>), grid, block, lds, st, p);
+            else hipLaunchKernelGGL((prefill_wg_kernel<D, G, 4, 4, false, false, true>), grid, block, lds, st, p);
+        }
+        return;
+    }
     if (p.ps_shift >= 0) hipLaunchKernelGGL((prefill_wg_kernel<D, G, NW, NBUF, true>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((prefill_wg_kernel<D, G, NW, NBUF, false>), grid, block, lds, st, p);
 }
 
 template <int D, int G>
 static void launch_prefill_wg(const PrefillParams& p, int max_extend_len, hipStream_t st) {
-    const int cfg = prefill_wg_cfg();
+    const int cfg = p.f16 ? 0 : prefill_wg_cfg();
     if constexpr (D == 64) {
         if (cfg == 42) return launch_prefill_wg_cfg<D, G, 4, 8>(p, max_extend_len, st);
         return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
@@ -738,7 +751,8 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
         return paged_rows_attn(q, q_row_stride, k_pool, v_pool, page_table, pt_row_stride, page_table_ids, nullptr, cu_q,
                                prefix_lens, B, out, o_row_stride, T, Hq, Hkv, D, page_size, scale, max_seq_len_hint,
                                kRowsMaxChunk, workspace, workspace_bytes, dtype, (hipStream_t)stream);
-    if (dtype != M355_DTYPE_BF16) return M355_ERR_UNSUPPORTED;
+    const bool f16 = dtype == M355_DTYPE_F16;          // IEEE half: the workgroup kernel only
+    if (dtype != M355_DTYPE_BF16 && !(f16 && prefill_mode() == 0)) return M355_ERR_UNSUPPORTED;
     if (D != 64 && D != 128) return M355_ERR_UNSUPPORTED;
     const int G = Hq / Hkv;
     if (G != 1 && G != 2 && G != 4 && G != 8) return M355_ERR_UNSUPPORTED;
@@ -756,6 +770,7 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     p.stamps = nullptr;
     p.ws = nullptr;
     p.splits = 1;
+    p.f16 = f16 ? 1 : 0;
     if (prefill_mode() == 0) {
         p.splits = prefill_splits(T, Hq, max_seq_len_hint);
         if (p.splits > 1) {
@@ -770,8 +785,10 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
         if (prefill_mode() == 2) launch_prefill<DD, GG>(p, st); else launch_prefill_wg<DD, GG>(p, max_extend_len, st); \
         if (p.splits > 1) { \
             const int64_t items = (int64_t)T * Hq; \
-            hipLaunchKernelGGL((prefill_merge_kernel<DD>), dim3((unsigned)((items * (DD / 4) + 255) / 256)), dim3(256), 0, st, \
-                               p.ws, p.out, p.o_stride, items, Hq, p.splits); \
+            if (f16) hipLaunchKernelGGL((prefill_merge_kernel<DD, true>), dim3((unsigned)((items * (DD / 4) + 255) / 256)), dim3(256), 0, st, \
+                                        p.ws, p.out, p.o_stride, items, Hq, p.splits); \
+            else hipLaunchKernelGGL((prefill_merge_kernel<DD>), dim3((unsigned)((items * (DD / 4) + 255) / 256)), dim3(256), 0, st, \
+                                    p.ws, p.out, p.o_stride, items, Hq, p.splits); \
         } \
         return check_launch(); }
     M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)

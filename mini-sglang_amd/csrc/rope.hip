@@ -16,22 +16,23 @@
 namespace m355 {
 
 #pragma clang fp contract(off)
+template <bool F16>
 __device__ __forceinline__ void rotate8(u32x4& lo, u32x4& hi, const float* __restrict__ c, const float* __restrict__ s) {
 #pragma clang fp contract(off)
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const float a0 = bf16_lo(lo[w]), a1 = bf16_hi(lo[w]);
-        const float b0 = bf16_lo(hi[w]), b1 = bf16_hi(hi[w]);
+        const float a0 = unpack16_lo<F16>(lo[w]), a1 = unpack16_hi<F16>(lo[w]);
+        const float b0 = unpack16_lo<F16>(hi[w]), b1 = unpack16_hi<F16>(hi[w]);
         const float c0 = c[2 * w], c1 = c[2 * w + 1], s0 = s[2 * w], s1 = s[2 * w + 1];
         const float y0 = a0 * c0 - b0 * s0, y1 = a1 * c1 - b1 * s1;
         const float z0 = b0 * c0 + a0 * s0, z1 = b1 * c1 + a1 * s1;
-        lo[w] = pack_bf16(y0, y1);
-        hi[w] = pack_bf16(z0, z1);
+        lo[w] = pack16<F16>(y0, y1);
+        hi[w] = pack16<F16>(z0, z1);
     }
 }
 
 // work items per token: (Hq + Hkv) * D/16 rotations, then Hkv * D/8 v-row chunks (only when pools are given)
-template <bool STORE>
+template <bool STORE, bool F16 = false>
 __global__ __launch_bounds__(256) void rope_kv_store_kernel(uint16_t* __restrict__ q, int64_t q_stride, uint16_t* __restrict__ k,
                                                             int64_t k_stride, const uint16_t* __restrict__ v, int64_t v_stride,
                                                             const int64_t* __restrict__ positions,
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(uint16_t* __restrict
             uint16_t* row = is_q ? q + t * q_stride + (int64_t)head * D : k + t * k_stride + (int64_t)(head - Hq) * D;
             u32x4 lo = *reinterpret_cast<const u32x4*>(row + c8 * 8);
             u32x4 hi = *reinterpret_cast<const u32x4*>(row + D / 2 + c8 * 8);
-            rotate8(lo, hi, cs, sn);
+            rotate8<F16>(lo, hi, cs, sn);
             *reinterpret_cast<u32x4*>(row + c8 * 8) = lo;
             *reinterpret_cast<u32x4*>(row + D / 2 + c8 * 8) = hi;
             if constexpr (STORE) {
@@ -97,7 +98,8 @@ extern "C" int m355_rope_kv_store(void* q, int64_t q_row_stride, void* k, int64_
     if (!q || !k || !positions || !cos_sin_cache || T < 0 || Hq <= 0 || Hkv <= 0 || max_position <= 0) return M355_ERR_INVALID_ARG;
     const bool store = k_pool != nullptr;
     if (store && (!v_pool || !v || !loc || S <= 0)) return M355_ERR_INVALID_ARG;
-    if (dtype != M355_DTYPE_BF16) return M355_ERR_UNSUPPORTED;
+    if (dtype != M355_DTYPE_BF16 && dtype != M355_DTYPE_F16) return M355_ERR_UNSUPPORTED;
+    const bool f16 = dtype == M355_DTYPE_F16;
     if (D <= 0 || D % 16) return M355_ERR_UNSUPPORTED;
     if (q_row_stride < (int64_t)Hq * D || k_row_stride < (int64_t)Hkv * D || q_row_stride % 8 || k_row_stride % 8) return M355_ERR_INVALID_ARG;
     if (store && (v_row_stride < (int64_t)Hkv * D || v_row_stride % 8)) return M355_ERR_INVALID_ARG;
@@ -107,6 +109,18 @@ extern "C" int m355_rope_kv_store(void* q, int64_t q_row_stride, void* k, int64_
     const int64_t per_tok = (int64_t)(Hq + Hkv) * (D / 16) + (store ? (int64_t)Hkv * (D / 8) : 0);
     int64_t blocks = ((int64_t)T * per_tok + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    if (f16) {
+        if (store)
+            hipLaunchKernelGGL((m355::rope_kv_store_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                               (uint16_t*)q, q_row_stride, (uint16_t*)k, k_row_stride, (const uint16_t*)v, v_row_stride, positions,
+                               cos_sin_cache, max_position, (uint16_t*)k_pool, (uint16_t*)v_pool, loc, T, Hq, Hkv, D, S);
+        else
+            hipLaunchKernelGGL((m355::rope_kv_store_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                               (uint16_t*)q, q_row_stride, (uint16_t*)k, k_row_stride, (const uint16_t*)nullptr, (int64_t)0, positions,
+                               cos_sin_cache, max_position, (uint16_t*)nullptr, (uint16_t*)nullptr, (const int64_t*)nullptr, T, Hq, Hkv,
+                               D, (int64_t)0);
+        return m355::check_launch();
+    }
     if (store)
         hipLaunchKernelGGL(m355::rope_kv_store_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (uint16_t*)q, q_row_stride, (uint16_t*)k, k_row_stride, (const uint16_t*)v, v_row_stride, positions,

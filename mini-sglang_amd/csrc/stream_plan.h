@@ -58,6 +58,6 @@ __device__ __forceinline__ void sstamp(const StreamParams& p, int k) {
 // MFMA attention kernel (decode_mfma.hip).  Its waves-per-CU is LDS-limited and depends on the token capacity.
 int mfma_waves_per_cu(int Hkv, int D, int G, int64_t cap);
 int mfma_rmin();                 // shortest range (tokens) the plan should make for it
-int launch_stream_mfma(const StreamParams& p, int D, int G, int64_t cap, hipStream_t st, bool stamp);
+int launch_stream_mfma(const StreamParams& p, int D, int G, int64_t cap, hipStream_t st, bool stamp, bool f16);
 
 }  // namespace m355

@@ -90,3 +90,22 @@ def test_graphed_decode_equals_the_eager_loop(model, ps):
     _, graphed = bob.three_phase(runner, prompts, 0, out_len, graph=True)
     assert torch.equal(eager, graphed)
     assert runner.kvcache.ring.snapshot() == runner.kvcache.free_pages
+
+
+def test_three_phase_in_half_precision():
+    """The same three-phase check with an IEEE-half model (Llama-2-style checkpoints): fp16 goes through the same
+    matrix-core kernels (rope + store, prefill, planned decode with its merge)."""
+    import bench_one_batch as bob
+    from harness.llama_shell import SHAPES, HarnessRunner
+    shape = SHAPES["tiny128"]
+    B, L, out_len, ps, cut = 3, 90, 6, 16, 48
+    runner = HarnessRunner(shape, ps, max_total_tokens=B * 2 * (L + out_len + 2 * ps) + 64 * ps, max_reqs=B,
+                           context_len=L + out_len + ps, dtype=torch.float16)
+    prompts = [p[:n] for p, n in zip(bob.synth_prompts(B, L, shape.vocab, seed=3), (90, 61, 77))]
+    logits3, ids3 = bob.three_phase(runner, prompts, cut, out_len)
+    bob.reset_pools(runner)
+    logits1, ids1 = bob.three_phase(runner, prompts, 0, out_len)
+    scale = float(logits1.float().abs().max())
+    assert logits3.dtype == torch.float16 and torch.isfinite(logits3).all() and scale > 0
+    assert float((logits3.float() - logits1.float()).abs().max()) <= 0.05 * scale
+    assert torch.equal(ids3[:, 0], ids1[:, 0]) or float((ids3 == ids1).float().mean()) > 0.8

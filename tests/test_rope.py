@@ -58,19 +58,20 @@ def test_hip_rope_bit_exact_on_reference_vectors(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("Hq,Hkv,D,T", [(32, 8, 64, 300), (32, 8, 128, 77), (8, 1, 128, 1), (4, 4, 64, 513)])
-def test_hip_rope_fused_store_matches_oracle(Hq, Hkv, D, T):
+def test_hip_rope_fused_store_matches_oracle(Hq, Hkv, D, T, dtype):
     from mi355_attn import ops
     max_pos, S = 4096, 2048
     cache = A.rope_cache_ref(D, max_pos, 500000.0)
     g = torch.Generator().manual_seed(T)
-    qkv = torch.randn((T, (Hq + 2 * Hkv) * D), generator=g).to(torch.bfloat16)      # packed projection output
+    qkv = torch.randn((T, (Hq + 2 * Hkv) * D), generator=g).to(dtype)                # packed projection output
     pos = torch.randint(0, max_pos, (T,), generator=g)
     loc = torch.randperm(S, generator=g)[:T]
     q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)                          # strided views
     q_want, k_want = A.rope_neox_ref(pos, q, k, D, cache)
-    kp = torch.randn((S, Hkv, D), generator=g).to(torch.bfloat16)
-    vp = torch.randn((S, Hkv, D), generator=g).to(torch.bfloat16)
+    kp = torch.randn((S, Hkv, D), generator=g).to(dtype)
+    vp = torch.randn((S, Hkv, D), generator=g).to(dtype)
     kp_want, vp_want = kp.clone(), vp.clone()
     A.write_kv_ref(kp_want, vp_want, loc, k_want.view(T, Hkv, D), v.reshape(T, Hkv, D))
     d_qkv = qkv.cuda()
