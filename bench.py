@@ -102,7 +102,7 @@ def main():
     import mi355_attn as m
     from mi355_attn import ops
 
-    from mi355_attn.tp import all_reduce_rows, shard_heads
+    from mi355_attn.tp import all_reduce_rows, row_parallel_linear, shard_heads
 
     tp = world
     shard = shard_heads(MODEL["Hq"], MODEL["Hkv"], MODEL["D"], tp, rank)    # refuses tp > num_kv_heads
@@ -245,6 +245,37 @@ def main():
                 "decode_B64": time_allreduce(torch.zeros((64, 4096), dtype=torch.bfloat16, device=dev), 50),
                 "prefill_T4863": time_allreduce(torch.zeros((4863, 4096), dtype=torch.bfloat16, device=dev), 10)}
 
+    # ---- f3, first measurement: o_proj (row-parallel GEMM) + its all-reduce, back to back against pipelined over
+    # row blocks (mi355_attn.tp.row_parallel_linear).  Llama-3-8B shape: hidden 4096, this rank's Hq*D input columns.
+    def time_o_proj(T, chunks, reps):
+        if rehearse and rank == 0:
+            print(f"[rehearsal] o_proj T={T} chunks={chunks}", file=sys.stderr, flush=True)
+        k_in = 4096 // tp
+        x = torch.randn((T, k_in), device=dev, dtype=torch.bfloat16)
+        w = torch.randn((4096, k_in), device=dev, dtype=torch.bfloat16) * 0.02
+        for _ in range(3):
+            row_parallel_linear(x, w, chunks)
+        fence()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(reps):
+            row_parallel_linear(x, w, chunks)
+        a1.record()
+        torch.cuda.synchronize()
+        us = torch.tensor([a0.elapsed_time(a1) * 1e3 / reps], device=dev, dtype=torch.float64)
+        dist.all_reduce(us, op=dist.ReduceOp.MAX)
+        return round(float(us.item()), 2)
+
+    o_proj = None
+    if tp > 1 and (not rehearse or os.environ.get("M355_BENCH_REHEARSE_OPROJ") == "1"):
+        try:
+            o_proj = {"shape": f"x [T, {4096 // tp}] @ w [4096, {4096 // tp}]^T bf16, SUM over {tp} ranks", "us": {
+                f"T{T}": {f"chunks{c}": time_o_proj(T, c, reps)
+                          for c in cs} for T, cs, reps in (((64, (1, 2), 2), (256, (1, 4), 2)) if rehearse else
+                                                           ((64, (1, 2), 50), (4863, (1, 2, 4, 8), 10)))}}
+        except Exception as e:      # noqa: BLE001 - a side measurement must not take the bench line down
+            o_proj = {"error": repr(e)[:200]}
+
     cpu = None
     if rank == 0 and tp == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(kv, pm, batch, q, lens_now, Hq, Hkv, D, ps)
@@ -272,6 +303,7 @@ def main():
         if allreduce is not None:
             line["allreduce_o_proj"] = allreduce
             line["allreduce_o_proj_llama3_8b"] = allreduce_cfg4
+            line["o_proj_all_reduce"] = o_proj
         print(json.dumps(line), flush=True)
     if tp > 1:
         dist.destroy_process_group()

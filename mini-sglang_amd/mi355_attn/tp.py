@@ -57,3 +57,31 @@ def all_reduce_rows(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
     return x
+
+
+def row_parallel_linear(x: torch.Tensor, w: torch.Tensor, chunks: int = 1,
+                        group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """o_proj / down_proj under TP (first cut): y = all_reduce_sum(x @ w.T), the pair
+    RowParallelLinear.forward issues back to back (layers/linear.py:228-232).
+
+    `chunks > 1` pipelines the two over row blocks of x: block i's all-reduce is handed to the collective's own stream
+    (`async_op=True`: RCCL orders it after the GEMM that produced the block) while the GEMM of block i+1 runs on the
+    caller's stream, so for prefill-size messages the xGMI transfer hides behind the matrix cores.  Every row is
+    reduced exactly once, by the same collective over the same ranks, so the result equals the unchunked one up to
+    the GEMM's own blocking.  Decode-size messages are latency-bound - chunking only adds collectives there - so
+    callers keep chunks=1 below a few thousand rows (bench.py N>1 reports both, `o_proj_all_reduce`)."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    T = x.shape[0]
+    chunks = max(1, min(int(chunks), T))
+    if not multi or chunks == 1:
+        return all_reduce_rows(torch.nn.functional.linear(x, w), group)
+    y = torch.empty((T, w.shape[0]), dtype=x.dtype, device=x.device)
+    step = -(-T // chunks)
+    pending = []
+    for lo in range(0, T, step):
+        blk = y[lo:lo + step]                                  # contiguous row block of the result: reduced in place
+        torch.matmul(x[lo:lo + step], w.t(), out=blk)
+        pending.append(dist.all_reduce(blk, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for work in pending:
+        work.wait()                                            # the caller's stream waits; the host does not block on RCCL
+    return y

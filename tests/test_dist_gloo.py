@@ -32,7 +32,7 @@ def _worker(rank: int, world: int, port: int, results):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import mi355_attn as m
         from mi355_attn.batch import plan_decode, plan_prefill
-        from mi355_attn.tp import all_reduce_rows, shard_heads
+        from mi355_attn.tp import all_reduce_rows, row_parallel_linear, shard_heads
         from oracle import attention_ref as A
         from oracle import memory_ref as M
 
@@ -105,6 +105,12 @@ def _worker(rank: int, world: int, port: int, results):
             want = o_full @ w_o
             assert torch.allclose(o_full[:, sh.q_columns()], o_local, atol=1e-6), "head shard differs from full run"
             assert torch.allclose(total, want, atol=1e-4, rtol=1e-4), float((total - want).abs().max())
+            # f3: the same product through the pipelined o_proj (row blocks reduced while the next block multiplies)
+            w_shard = w_o[sh.q_columns()].t().contiguous()        # [hidden, local Hq*D], the RowParallelLinear weight
+            for chunks in (1, 3, 64):
+                piped = row_parallel_linear(o_local, w_shard, chunks=chunks)
+                assert piped.shape == want.shape
+                assert torch.allclose(piped, want, atol=1e-4, rtol=1e-4), (chunks, float((piped - want).abs().max()))
             # the local pool holds exactly this rank's kv-head slice of the full pool
             assert torch.equal(kp, full_k[:, sh.kv_head_start: sh.kv_head_start + sh.num_kv_heads])
         dist.barrier()
