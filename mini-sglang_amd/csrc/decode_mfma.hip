@@ -317,41 +317,25 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
         __syncthreads();                                 // rec / q rows / slots are rewritten next
     };
 
-    // A wave with more than one range (long streams: k rounds of the grid-stride loop) asks for the NEXT range's record
-    // and whole slot slab while it streams the current one, so a round starts without the two dependent plan
-    // latencies (record, then the slots past the speculative ones) the first round pays.
-    constexpr int kPre = kRMax / kWave;
-    int32_t rv = 0, sv[kPre];
-    bool pre = false;                                    // wave-uniform: rv / sv hold range r already
     for (int r = w; r < p.max_ranges; r += p.nwh) {
         // ---- the record and (speculatively) the first slots in one round of loads
+        const int32_t* grec = plan + p.off_rec + (int64_t)r * kRec;
         const int32_t* gslots = plan + p.off_slots + (int64_t)r * kRMax;
-        if (!pre) {
-            const int32_t* grec = plan + p.off_rec + (int64_t)r * kRec;
-            if (lane < kRec) rv = grec[lane];
+        int32_t rv = 0, sv[kSpec];
+        if (lane < kRec) rv = grec[lane];
 #pragma unroll
-            for (int k = 0; k < kSpec; ++k) sv[k] = gslots[lane + kWave * k];
-        }
+        for (int k = 0; k < kSpec; ++k) sv[k] = gslots[lane + kWave * k];
         if (lane < kRec) rec[lane] = rv;
 #pragma unroll
-        for (int k = 0; k < kPre; ++k)
-            if ((k < kSpec || pre) && lane + kWave * k < slots_cap) slots[lane + kWave * k] = sv[k];
+        for (int k = 0; k < kSpec; ++k)
+            if (lane + kWave * k < slots_cap) slots[lane + kWave * k] = sv[k];
         __syncthreads();
         const int32_t nt = __builtin_amdgcn_readfirstlane(rec[0]);
         const int32_t np_rec = __builtin_amdgcn_readfirstlane(rec[1]);
         if (nt == 0) break;                              // past the last range
-        if (!pre && nt > kSpec * kWave) {
+        if (nt > kSpec * kWave) {
             for (int i = kSpec * kWave + lane; i < nt && i < slots_cap; i += kWave) slots[i] = gslots[i];
             __syncthreads();
-        }
-        pre = r + p.nwh < p.max_ranges;
-        if (pre) {                                       // (a slab past a range's length holds stale words: never indexed)
-            const int32_t* grec2 = plan + p.off_rec + (int64_t)(r + p.nwh) * kRec;
-            const int32_t* gslots2 = gslots + (int64_t)p.nwh * kRMax;
-            rv = lane < kRec ? grec2[lane] : 0;
-#pragma unroll
-            for (int k = 0; k < kPre; ++k)
-                if (lane + kWave * k < slots_cap) sv[k] = gslots2[lane + kWave * k];
         }
         sstamp<STAMP>(p, 1);
         // pieces come from the record, or - more than kMaxPieces requests in the range - from scanning cum in rounds
