@@ -24,6 +24,10 @@
 
 #include "stream_plan.h"
 
+#ifndef M355_DECODE_POLICY
+#define M355_DECODE_POLICY 1      // K/V are streamed once per step: non-temporal loads (common.h glds16p)
+#endif
+#define M355_DMA16 glds16p<M355_DECODE_POLICY>
 namespace m355 {
 
 constexpr float kLazyMax = 8.f;                 // log2 units
@@ -132,14 +136,14 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
 #pragma unroll
                 for (int i = 0; i < M::NI; ++i) {
                     const bool fresh = tt[i] == l_len - 1;
-                    glds16((fresh ? l_knew : kbase + ro[i]) + koff[i], sbase + 1024 * i);
-                    glds16((fresh ? l_vnew : vbase + ro[i]) + voff[i], sbase + M::TILEB + 1024 * i);
+                    M355_DMA16((fresh ? l_knew : kbase + ro[i]) + koff[i], sbase + 1024 * i);
+                    M355_DMA16((fresh ? l_vnew : vbase + ro[i]) + voff[i], sbase + M::TILEB + 1024 * i);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < M::NI; ++i) {
-                    glds16(kbase + ro[i] + koff[i], sbase + 1024 * i);
-                    glds16(vbase + ro[i] + voff[i], sbase + M::TILEB + 1024 * i);
+                    M355_DMA16(kbase + ro[i] + koff[i], sbase + 1024 * i);
+                    M355_DMA16(vbase + ro[i] + voff[i], sbase + M::TILEB + 1024 * i);
                 }
             }
             ++issued;

@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmi355attn.so")
+LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libmi355attn.so")   # (override: dev A/B builds)
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
