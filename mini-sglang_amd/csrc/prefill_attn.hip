@@ -22,6 +22,9 @@
 #include "common.h"
 #include "paged_rows.h"
 
+#ifndef M355_PREFILL_POLICY
+#define M355_PREFILL_POLICY 0     // K/V tiles are re-read by the row blocks of the same XCD through L2: default policy
+#endif
 namespace m355 {
 
 struct PrefillParams {
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         const int i = wid + NW * (x % HP);                         // wave-uniform
         const int row = i * W::RPI + drow;
         const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
-        glds16((is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch,
+        glds16p<M355_PREFILL_POLICY>((is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch,
                lds0 + (is_v ? NBUF * W::TILEB : 0) + (buf0 + x / HP) * W::TILEB + 1024 * i);
     };
     auto issue_pair = [&](const int pair, const int buf0) {         // prologue: everything at once
