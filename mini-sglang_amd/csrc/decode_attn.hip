@@ -248,8 +248,8 @@ __global__ __launch_bounds__(64, W) void decode_split_kernel(const DecodeParams 
                 kt[u] = u32x4{(uint32_t)off, 0x3f803f80u, 0x3f803f80u, (uint32_t)it};
                 vt[u] = kt[u];
             } else {
-                kt[u] = *reinterpret_cast<const u32x4*>(p.k_pool + off);
-                vt[u] = *reinterpret_cast<const u32x4*>(p.v_pool + off);
+                kt[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.k_pool + off));   // read once per step: see glds16p
+                vt[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.v_pool + off));
             }
         }
     };
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(64, W) void decode_split_lds_kernel(const DecodePar
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t off = (int64_t)slots[(it * U + u) * NT + tsub] * p.row_elems;
-            glds16(kbase + off, dst + u * 2048);
-            glds16(vbase + off, dst + u * 2048 + 1024);
+            glds16p<1>(kbase + off, dst + u * 2048);
+            glds16p<1>(vbase + off, dst + u * 2048 + 1024);
         }
     };
     auto consume = [&](int it) {

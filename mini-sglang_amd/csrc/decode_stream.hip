@@ -269,8 +269,8 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
                 int tt = lit * TPI + u * NT + tsub;
                 tt = tt < l_len ? tt : l_len - 1;         // clamp: the row is masked through the score bias
                 const int64_t off = (int64_t)slots[l_start + tt] * p.row_elems + lane_off;
-                kt[u] = *reinterpret_cast<const u32x4*>(p.k_pool + off);
-                vt[u] = *reinterpret_cast<const u32x4*>(p.v_pool + off);
+                kt[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.k_pool + off));   // read once per step: see glds16p
+                vt[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.v_pool + off));
             }
             ++lit;
             if (lit * TPI >= l_len) {                     // next piece
