@@ -11,7 +11,7 @@ struct Stamp { unsigned long long t0, t1; uint32_t xcc, pad; };
 
 // MODE 0: contiguous 1 KiB per instruction, wave-private contiguous span.  MODE 1: head column (8 rows x 128 B) of
 // shuffled 16 KiB pages, heads rotated over the XCDs like the decode kernel.
-template <int R, int MODE>
+template <int R, int MODE, int NT = 0>
 __global__ __launch_bounds__(64) void stream(const uint8_t* __restrict__ src, const int* __restrict__ pages, int ppw,
                                              int nheads, Stamp* st) {
     extern __shared__ uint8_t smem[];
@@ -29,7 +29,9 @@ __global__ __launch_bounds__(64) void stream(const uint8_t* __restrict__ src, co
         const uint8_t* a = MODE == 1 ? src + (size_t)pg * 16384 + (size_t)(i * 8 + lane / 8) * 1024 + h * 128 + (lane % 8) * 16
                                      : src + (size_t)pg * 16384 + i * 1024 + lane * 16;
         uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        if constexpr (NT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(a), "s"(lds0 + slot * 1024) : "memory");
+        else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(a), "s"(lds0 + slot * 1024) : "memory");
         ++issued;
     };
@@ -91,6 +93,19 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         stream<16, 0><<<waves, 64, 16 * 1024>>>(d, dp, npages / waves, 1, ds);
         report("contiguous 2.4 GB");
+    }
+    // non-temporal loads (what the decode kernel uses since the end of round 1)
+    for (int rep = 0; rep < 2; ++rep) {
+        stream<16, 1, 1><<<waves, 64, 16 * 1024>>>(d, dp, npages / 256, 8, ds);
+        report("head-column 2.4 GB, nt");
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        stream<16, 0, 1><<<waves, 64, 16 * 1024>>>(d, dp, npages / waves, 1, ds);
+        report("contiguous 2.4 GB, nt");
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        stream<16, 1, 1><<<waves, 64, 16 * 1024>>>(d, dp + (4 + rep) * 256 * 36, 36, 8, ds);
+        report("head-column 151 MB, nt");
     }
     return 0;
 }
