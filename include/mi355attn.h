@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define M355_VERSION 100 /* 0.1.0 */
+#define M355_VERSION 200 /* 0.2.0 */
 
 enum {
     M355_OK = 0,
@@ -70,8 +70,12 @@ int m355_out_cache_loc(const int32_t *page_table, int64_t pt_row_stride, const i
  *   cu_q (int32, device, [B+1]) = exclusive prefix sum of (seq_len - prefix_len)
  * Effects: page_table[row_r, 0:npages_r] = its pages (PageManager.write_ppns_prefill,
  * memory/page_manager.py:45-46); positions[cu_q[r] + j] = prefix_len_r + j;
- * row_of_token[...] = row_r; out_cache_loc[...] as above.  All outputs int64. */
-int m355_prefill_prepare(int32_t *page_table, int64_t pt_row_stride, const int32_t *plan,
+ * row_of_token[...] = row_r; out_cache_loc[...] as above.  All outputs int64.
+ * pt_cols = columns of the table (PageManager.max_page_num, memory/page_manager.py:21; <= pt_row_stride): entries
+ * at or past it are not written and the token's out_cache_loc is -1, so a request longer than the table is wide can
+ * never spill into the next request's row (the reference raises on the shape mismatch at page_manager.py:46; the
+ * host planner here raises first). */
+int m355_prefill_prepare(int32_t *page_table, int64_t pt_row_stride, int32_t pt_cols, const int32_t *plan,
                          const int32_t *pages, const int32_t *cu_q, int32_t B, int32_t page_size,
                          int64_t *positions, int64_t *row_of_token, int64_t *out_cache_loc,
                          void *stream);
@@ -81,8 +85,9 @@ int m355_prefill_prepare(int32_t *page_table, int64_t pt_row_stride, const int32
  *     if new_pages[b] >= 0: page_table[rows[b], positions[b] / page_size] = new_pages[b]
  *     out_cache_loc[b] = page_table[rows[b], positions[b] / page_size] * page_size + positions[b] % page_size
  * new_pages[b] is the page the host allocator popped for request b, or -1 when the new token
- * still fits its last page (memory/kvcache.py:49-56). */
-int m355_decode_prepare(int32_t *page_table, int64_t pt_row_stride, const int64_t *rows,
+ * still fits its last page (memory/kvcache.py:49-56).  pt_cols: as m355_prefill_prepare (a position past the table's
+ * width writes nothing and gets out_cache_loc -1; the reference raises an index error at page_manager.py:54). */
+int m355_decode_prepare(int32_t *page_table, int64_t pt_row_stride, int32_t pt_cols, const int64_t *rows,
                         const int64_t *seq_lens_in, int64_t *seq_lens_out, const int32_t *new_pages,
                         int32_t B, int32_t page_size, int64_t *positions, int64_t *out_cache_loc,
                         void *stream);
@@ -102,7 +107,7 @@ int m355_page_ring_push(int32_t *ring, int64_t *state, int32_t capacity, const i
  * page off the ring iff seq_lens_in[b] % page_size == 0 (its new token starts a page); outputs as
  * m355_decode_prepare; state advances by the number of pages taken.  The caller guarantees that the ring holds
  * enough pages (the host knows count and lengths). */
-int m355_decode_prepare_ring(int32_t *page_table, int64_t pt_row_stride, const int64_t *rows,
+int m355_decode_prepare_ring(int32_t *page_table, int64_t pt_row_stride, int32_t pt_cols, const int64_t *rows,
                              const int64_t *seq_lens_in, int64_t *seq_lens_out, const int32_t *ring,
                              int64_t *state, int32_t capacity, int32_t B, int32_t page_size,
                              int64_t *positions, int64_t *out_cache_loc, void *stream);

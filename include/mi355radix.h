@@ -3,8 +3,10 @@
  * Host-only C ABI (no GPU, no torch types): token ids in, physical page numbers out.  Same results as the
  * reference's Python tree, operation for operation (memory/radix_cache.py:73-371): keys are compared in
  * page_size-token chunks, a child is found by its first chunk (:85-90), match_prefix splits a node that matches
- * only in part and - exactly like the reference (:263-267) - continues from the new upper node without consuming
- * the key, eviction removes unlocked leaves in least-recently-used order (:202-221).  The LRU stamp is a strictly
+ * only in part, eviction removes unlocked leaves in least-recently-used order (:202-221).  After such a split
+ * the walk stops; the reference (:263-267) continues from the new upper node without consuming the key and can then
+ * return pages of tokens the key does not hold ("abab" cached, "abc" queried) - m355r_set_reference_walk(tree, 1)
+ * restores that walk for parity tests against the reference's own traces.  The LRU stamp is a strictly
  * increasing counter instead of time.time().  One tree per handle; calls on one handle must not overlap. */
 #ifndef MI355RADIX_H
 #define MI355RADIX_H
@@ -19,10 +21,11 @@ int m355r_version(void);
 void *m355r_create(int32_t page_size);
 void m355r_destroy(void *tree);
 void m355r_reset(void *tree);
+void m355r_set_reference_walk(void *tree, int32_t on);   /* default 0: stop at a split (see above) */
 
 /* match_prefix (radix_cache.py:101-125).  `key` is cut to a multiple of page_size.  Writes the matched pages to
  * out_pages (up to cap) and the last node reached to *node (an opaque handle for the lock calls; the root for an
- * empty key).  Returns the number of matched pages - which the reference's walk after a split can make LARGER than
+ * empty key).  Returns the number of matched pages - which, with the reference walk switched on, can be LARGER than
  * the key's page count; when it exceeds cap, fetch the full list with m355r_last_match (the tree is not walked
  * again) - or -1 on a bad argument. */
 int64_t m355r_match_prefix(void *tree, const int64_t *key, int64_t n_tokens, int32_t *out_pages, int64_t cap,

@@ -26,7 +26,10 @@ __device__ __forceinline__ int find_req_by(const int32_t* key, int stride, int B
     return lo;
 }
 
-__global__ __launch_bounds__(256) void prefill_prepare_kernel(int32_t* __restrict__ page_table, int64_t pt_stride,
+// A request longer than the table is wide (pt_cols columns) never writes past its row: the out-of-range entries are
+// dropped and its out_cache_loc is -1 (m355_kv_store skips it).  The host planner refuses such a batch first
+// (mi355_attn/batch.py; the reference fails on the shape mismatch at memory/page_manager.py:46).
+__global__ __launch_bounds__(256) void prefill_prepare_kernel(int32_t* __restrict__ page_table, int64_t pt_stride, int32_t pt_cols,
                                                               const int32_t* __restrict__ plan,
                                                               const int32_t* __restrict__ pages,
                                                               const int32_t* __restrict__ cu_q, int32_t B, int32_t ps,
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void prefill_prepare_kernel(int32_t* __restric
             // requests that own zero pages share a page_off with their successor: take the LAST such r whose
             // range is non-empty, i.e. the largest r with page_off[r] <= i - that is what find_req_by returns.
             const int32_t j = (int32_t)i - plan[r * 4 + 3];
-            page_table[(int64_t)plan[r * 4 + 0] * pt_stride + j] = pages[i];
+            if (j < pt_cols) page_table[(int64_t)plan[r * 4 + 0] * pt_stride + j] = pages[i];
         } else {
             const int32_t t = (int32_t)(i - total_pages);
             const int r = find_req_by(cu_q, 1, B, t);          // largest r with cu_q[r] <= t (skips empty requests)
@@ -52,12 +55,12 @@ __global__ __launch_bounds__(256) void prefill_prepare_kernel(int32_t* __restric
             const int64_t vpn = pos / ps;
             positions[t] = pos;
             row_of_token[t] = row;
-            out_cache_loc[t] = (int64_t)pages[plan[r * 4 + 3] + vpn] * ps + (pos - vpn * ps);
+            out_cache_loc[t] = vpn < pt_cols ? (int64_t)pages[plan[r * 4 + 3] + vpn] * ps + (pos - vpn * ps) : (int64_t)-1;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void decode_prepare_kernel(int32_t* __restrict__ page_table, int64_t pt_stride,
+__global__ __launch_bounds__(256) void decode_prepare_kernel(int32_t* __restrict__ page_table, int64_t pt_stride, int32_t pt_cols,
                                                              const int64_t* __restrict__ rows, const int64_t* seq_lens_in,
                                                              int64_t* seq_lens_out, const int32_t* __restrict__ new_pages, int32_t B, int32_t ps,
                                                              int64_t* __restrict__ positions,
@@ -67,12 +70,13 @@ __global__ __launch_bounds__(256) void decode_prepare_kernel(int32_t* __restrict
     const int64_t L = seq_lens_in[b] + 1;                 // batch.py:325
     const int64_t pos = L - 1;                            // batch.py:326
     const int64_t vpn = pos / ps;
+    seq_lens_out[b] = L;
+    positions[b] = pos;
+    if (vpn >= pt_cols) { out_cache_loc[b] = -1; return; }     // past the table's width: nothing written (see above)
     int32_t* entry = page_table + rows[b] * pt_stride + vpn;
     int32_t page = new_pages[b];
     if (page >= 0) *entry = page;                         // batch.py:331-337
     else page = *entry;
-    seq_lens_out[b] = L;
-    positions[b] = pos;
     out_cache_loc[b] = (int64_t)page * ps + (pos - vpn * ps);   // batch.py:341-343
 }
 
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void page_ring_push_kernel(int32_t* __restrict
 
 // One workgroup walks the batch in order: a request whose new token starts a page takes the next page off the ring
 // (engine/batch.py:325-343 with memory/kvcache.py:49-56 folded in); everything else is decode_prepare_kernel.
-__global__ __launch_bounds__(1024) void decode_prepare_ring_kernel(int32_t* __restrict__ page_table, int64_t pt_stride,
+__global__ __launch_bounds__(1024) void decode_prepare_ring_kernel(int32_t* __restrict__ page_table, int64_t pt_stride, int32_t pt_cols,
                                                                    const int64_t* __restrict__ rows, const int64_t* seq_lens_in,
                                                                    int64_t* seq_lens_out, const int32_t* __restrict__ ring,
                                                                    int64_t* __restrict__ state, int32_t cap, int32_t B, int32_t ps,
@@ -123,13 +127,17 @@ __global__ __launch_bounds__(1024) void decode_prepare_ring_kernel(int32_t* __re
         before += __popcll(mask & ((1ull << lane) - 1));
         if (b < B) {
             const int64_t vpn = pos / ps;
-            int32_t* entry = page_table + rows[b] * pt_stride + vpn;
-            int32_t page;
-            if (need) { page = ring[(head + before) % cap]; *entry = page; }
-            else page = *entry;
             seq_lens_out[b] = pos + 1;
             positions[b] = pos;
-            out_cache_loc[b] = (int64_t)page * ps + (pos - vpn * ps);
+            if (vpn < pt_cols) {
+                int32_t* entry = page_table + rows[b] * pt_stride + vpn;
+                int32_t page;
+                if (need) { page = ring[(head + before) % cap]; *entry = page; }
+                else page = *entry;
+                out_cache_loc[b] = (int64_t)page * ps + (pos - vpn * ps);
+            } else {
+                out_cache_loc[b] = -1;                    // past the table's width (the page is still taken: FIFO order holds)
+            }
         }
         taken += total;
         __syncthreads();                                  // wave_sum is rewritten next round
@@ -162,16 +170,16 @@ extern "C" int m355_page_ring_push(int32_t* ring, int64_t* state, int32_t capaci
     return m355::check_launch();
 }
 
-extern "C" int m355_decode_prepare_ring(int32_t* page_table, int64_t pt_row_stride, const int64_t* rows,
+extern "C" int m355_decode_prepare_ring(int32_t* page_table, int64_t pt_row_stride, int32_t pt_cols, const int64_t* rows,
                                         const int64_t* seq_lens_in, int64_t* seq_lens_out, const int32_t* ring,
                                         int64_t* state, int32_t capacity, int32_t B, int32_t page_size, int64_t* positions,
                                         int64_t* out_cache_loc, void* stream) {
     if (B == 0) return M355_OK;
     if (!page_table || !rows || !seq_lens_in || !seq_lens_out || !ring || !state || !positions || !out_cache_loc || B < 0 ||
-        page_size <= 0 || pt_row_stride <= 0 || capacity <= 0)
+        page_size <= 0 || pt_row_stride <= 0 || pt_cols <= 0 || pt_cols > pt_row_stride || capacity <= 0)
         return M355_ERR_INVALID_ARG;
     hipLaunchKernelGGL(m355::decode_prepare_ring_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, page_table, pt_row_stride,
-                       rows, seq_lens_in, seq_lens_out, ring, state, capacity, B, page_size, positions, out_cache_loc);
+                       pt_cols, rows, seq_lens_in, seq_lens_out, ring, state, capacity, B, page_size, positions, out_cache_loc);
     return m355::check_launch();
 }
 
@@ -187,27 +195,27 @@ extern "C" int m355_out_cache_loc(const int32_t* page_table, int64_t pt_row_stri
     return m355::check_launch();
 }
 
-extern "C" int m355_prefill_prepare(int32_t* page_table, int64_t pt_row_stride, const int32_t* plan, const int32_t* pages,
+extern "C" int m355_prefill_prepare(int32_t* page_table, int64_t pt_row_stride, int32_t pt_cols, const int32_t* plan, const int32_t* pages,
                                     const int32_t* cu_q, int32_t B, int32_t page_size, int64_t* positions,
                                     int64_t* row_of_token, int64_t* out_cache_loc, void* stream) {
     if (B == 0) return M355_OK;
     if (!page_table || !plan || !pages || !cu_q || !positions || !row_of_token || !out_cache_loc || B < 0 ||
-        page_size <= 0 || pt_row_stride <= 0)
+        page_size <= 0 || pt_row_stride <= 0 || pt_cols <= 0 || pt_cols > pt_row_stride)
         return M355_ERR_INVALID_ARG;
     // the host does not pass T/total pages (they sit in the device plan); size the grid generously and grid-stride
     hipLaunchKernelGGL(m355::prefill_prepare_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, page_table,
-                       pt_row_stride, plan, pages, cu_q, B, page_size, positions, row_of_token, out_cache_loc);
+                       pt_row_stride, pt_cols, plan, pages, cu_q, B, page_size, positions, row_of_token, out_cache_loc);
     return m355::check_launch();
 }
 
-extern "C" int m355_decode_prepare(int32_t* page_table, int64_t pt_row_stride, const int64_t* rows,
+extern "C" int m355_decode_prepare(int32_t* page_table, int64_t pt_row_stride, int32_t pt_cols, const int64_t* rows,
                                    const int64_t* seq_lens_in, int64_t* seq_lens_out, const int32_t* new_pages, int32_t B,
                                    int32_t page_size, int64_t* positions, int64_t* out_cache_loc, void* stream) {
     if (B == 0) return M355_OK;
     if (!page_table || !rows || !seq_lens_in || !seq_lens_out || !new_pages || !positions || !out_cache_loc || B < 0 || page_size <= 0 ||
-        pt_row_stride <= 0)
+        pt_row_stride <= 0 || pt_cols <= 0 || pt_cols > pt_row_stride)
         return M355_ERR_INVALID_ARG;
     hipLaunchKernelGGL(m355::decode_prepare_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, page_table,
-                       pt_row_stride, rows, seq_lens_in, seq_lens_out, new_pages, B, page_size, positions, out_cache_loc);
+                       pt_row_stride, pt_cols, rows, seq_lens_in, seq_lens_out, new_pages, B, page_size, positions, out_cache_loc);
     return m355::check_launch();
 }

@@ -1,6 +1,7 @@
 // Paged radix tree, native host code (include/mi355radix.h).  Mirrors mi355_attn/radix_cache.py - itself pinned to the
 // reference's traces (memory/radix_cache.py:73-371) - operation for operation, including the order in which nodes
-// are stamped (the stamp order IS the eviction order).
+// are stamped (the stamp order IS the eviction order).  match_prefix stops at a split unless the reference's walk is
+// asked for (m355r_set_reference_walk).
 #include "../../include/mi355radix.h"
 
 #include <algorithm>
@@ -33,6 +34,7 @@ struct Node {
 
 struct Tree {
     int32_t ps;
+    bool reference_walk = false;                            // match_prefix goes on after a split like the reference (:263-267)
     Node* root = nullptr;
     uint64_t clock = 0;
     int64_t evictable = 0, protected_ = 0, nodes = 0;
@@ -91,6 +93,7 @@ int m355r_version(void) { return 1; }
 void* m355r_create(int32_t page_size) { return page_size > 0 ? new Tree(page_size) : nullptr; }
 void m355r_destroy(void* t) { delete static_cast<Tree*>(t); }
 void m355r_reset(void* t) { if (t) static_cast<Tree*>(t)->reset(); }
+void m355r_set_reference_walk(void* t, int32_t on) { if (t) static_cast<Tree*>(t)->reference_walk = on != 0; }
 
 int64_t m355r_match_prefix(void* tp, const int64_t* key, int64_t n, int32_t* out, int64_t cap, int64_t* node_out) {
     Tree* t = static_cast<Tree*>(tp);
@@ -110,8 +113,9 @@ int64_t m355r_match_prefix(void* tp, const int64_t* key, int64_t n, int32_t* out
         t->touch(child);
         const int64_t m = t->match_len(child->key, k, left);
         if (m < (int64_t)child->key.size()) {
-            node = t->split(child, m);            // the walk goes on from the new upper node WITHOUT consuming the key
+            node = t->split(child, m);            // the match ends inside this child: split there and stop
             emit(node->value);
+            if (!t->reference_walk) break;        // (reference: goes on from the new upper node WITHOUT consuming the key)
         } else {
             emit(child->value);
             node = child;

@@ -20,14 +20,14 @@ SIGNATURES = {
     "m355_kv_store": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
                                 c_int32, c_int32, c_int64, c_int32, c_void_p]),
     "m355_out_cache_loc": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
-    "m355_prefill_prepare": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
+    "m355_prefill_prepare": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
-    "m355_decode_prepare": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+    "m355_decode_prepare": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p, c_void_p]),
     "m355_page_ring_init": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "m355_page_ring_pop": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "m355_page_ring_push": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
-    "m355_decode_prepare_ring": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+    "m355_decode_prepare_ring": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                            c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "m355_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "m355_decode_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

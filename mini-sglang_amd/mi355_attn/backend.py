@@ -34,6 +34,7 @@ class ForwardMetadata:
     workspace: Optional[torch.Tensor] = None
     ws: Optional[torch.Tensor] = None              # planned decode: the workspace of this forward ...
     ws_key: Optional[tuple] = None                 # ... and the (B, Hq, Hkv, D) it was sized for
+    first_layer: Optional[int] = None              # layer_id of the first layer that used this metadata
 
 
 def pick_decode_chunk(total_tokens: int, num_kv_heads: int) -> int:
@@ -108,11 +109,21 @@ class MI355AttnBackend:
         k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
         ops.kv_store(k_pool, v_pool, batch.out_cache_loc, k, v)        # replaces KVCache.write_kv
 
+    def _new_forward(self, md, layer) -> bool:
+        """True when `layer` is the layer that first used `md`: the model has come round again, i.e. a new forward
+        began without init_forward_metadata (legal against the torch-native backend, whose hook is a no-op,
+        torch_native_backend.py:21-23).  The per-forward plan / lengths are then stale and must be rebuilt."""
+        if md.first_layer is None:
+            md.first_layer = layer.layer_id
+            return False
+        return md.first_layer == layer.layer_id
+
     def forward_decode(self, q, k, v, layer, batch):
         md = self.forward_metadata
-        if md is None or not md.decode:
+        if md is None or not md.decode or self._new_forward(md, layer):
             self.init_forward_metadata(batch)
             md = self.forward_metadata
+            md.first_layer = layer.layer_id
         k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
         B = q.shape[0]
         fuse = (self.decode_mode == "planned" and self.fused_store and k is not None and k.dtype == k_pool.dtype
@@ -140,9 +151,10 @@ class MI355AttnBackend:
 
     def forward_extend(self, q, k, v, layer, batch):
         md = self.forward_metadata
-        if md is None or md.decode:
+        if md is None or md.decode or self._new_forward(md, layer):
             self.init_forward_metadata(batch)
             md = self.forward_metadata
+            md.first_layer = layer.layer_id
         self._store_kv(k, v, layer, batch)       # first: the new tokens' K/V are read back from the pool
         k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
         T = q.shape[0]

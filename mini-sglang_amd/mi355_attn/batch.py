@@ -127,12 +127,18 @@ class PrefillPlan:
 def plan_prefill(reqs: List[Req], page_manager, kvcache) -> PrefillPlan:
     """Host half of Batch.prepare_for_prefill (engine/batch.py:244-292): same rows, same pages, same order."""
     ps = page_manager.page_size
-    rows = page_manager.allocate(len(reqs))                                          # batch.py:248
     seq_lens = [len(r.fill_ids) for r in reqs]                                       # :255
     prefix_lens = [len(r.prefix_ppns) * ps for r in reqs]                            # :256
-    fresh = kvcache.allocate_pages_prefill(seq_lens, prefix_lens)                    # :276-278
-    if any(f is None for f in fresh):
+    # Everything that can fail is checked BEFORE a row or a page is taken, so a refused batch leaks nothing.
+    width = getattr(page_manager, "max_page_num", None)
+    if width is not None and seq_lens and -(-max(seq_lens) // ps) > width:
+        raise RuntimeError(f"request of {max(seq_lens)} tokens needs more than the page table's {width} columns "
+                           "(max_context_len); the reference fails on the row write, memory/page_manager.py:46")
+    need = sum(-(-s // ps) - -(-p // ps) for s, p in zip(seq_lens, prefix_lens))
+    if need > kvcache.available_page_num():
         raise RuntimeError("KV pool exhausted during prefill (the reference would crash on None pages here)")
+    rows = page_manager.allocate(len(reqs))                                          # batch.py:248
+    fresh = kvcache.allocate_pages_prefill(seq_lens, prefix_lens)                    # :276-278
     ids, pages, page_off, cu_q = [], [], [0], [0]
     for r, row, pl, sl, new in zip(reqs, rows, prefix_lens, seq_lens, fresh):
         r.page_table_id = row                                                        # :282
@@ -146,12 +152,22 @@ def plan_prefill(reqs: List[Req], page_manager, kvcache) -> PrefillPlan:
                        np.asarray(cu_q, dtype=np.int32))
 
 
-def plan_decode(seq_lens_host: List[int], kvcache) -> tuple:
+def _check_decode_width(lens: np.ndarray, page_size: int, page_manager) -> None:
+    """A decode step must not grow a request past the page table's width (the reference's scatter raises an index
+    error there, memory/page_manager.py:54)."""
+    width = getattr(page_manager, "max_page_num", None)
+    if width is not None and lens.size and -(-int(lens.max()) // page_size) > width:
+        raise RuntimeError(f"decode step would grow a request to {int(lens.max())} tokens: more than the page table's "
+                           f"{width} columns (max_context_len)")
+
+
+def plan_decode(seq_lens_host: List[int], kvcache, page_manager=None) -> tuple:
     """Host half of Batch.prepare_for_decode (engine/batch.py:325-337): bump the lengths and pop one page for
     every request whose new token starts a page, in batch order like the reference's per-request loop
     (memory/kvcache.py:49-56: ceil(s/ps) - ceil((s-1)/ps) pages, i.e. one iff (s-1) % ps == 0) - vectorised, no
     per-request Python.  Returns (new seq_lens, int32 [B] new page or -1)."""
     lens = np.asarray(seq_lens_host, dtype=np.int64) + 1
+    _check_decode_width(lens, kvcache.page_size, page_manager)
     need = (lens - 1) % kvcache.page_size == 0
     pages = kvcache._allocate_pages(int(need.sum()))
     if pages is None:
@@ -227,7 +243,7 @@ class Batch:
             self.seq_lens, self.positions, self.out_cache_loc = ops.decode_prepare_ring(
                 self.page_manager.page_table, self.page_table_ids, self.seq_lens, self.kvcache.ring, self.page_size)
         else:
-            self.seq_lens_host, new_pages = plan_decode(self.seq_lens_host, self.kvcache)
+            self.seq_lens_host, new_pages = plan_decode(self.seq_lens_host, self.kvcache, self.page_manager)
             self.seq_lens, self.positions, self.out_cache_loc = ops.decode_prepare(
                 self.page_manager.page_table, self.page_table_ids, self.seq_lens, _h2d(new_pages, self.device),
                 self.page_size)
@@ -240,6 +256,7 @@ class Batch:
         if self.seq_lens_host is None:
             self.seq_lens_host = [int(x) for x in self.seq_lens.tolist()]
         lens = np.asarray(self.seq_lens_host, dtype=np.int64)
+        _check_decode_width(lens + 1, self.page_size, self.page_manager)
         if not self.kvcache.take_on_device(int((lens % self.page_size == 0).sum())):
             raise RuntimeError("KV pool exhausted during decode (call check_decode_mem / retract_decode first)")
         self.seq_lens_host = (lens + 1).tolist()
@@ -301,7 +318,8 @@ class Batch:
 
     def retract_decode(self, retract_decode_steps: int = 20):
         """Give the pages of the most recently started requests back until the rest can keep decoding
-        (batch.py:393-464, with its undefined `residual_size` resolved to the evident max(0, .) clamp)."""
+        (batch.py:393-464, with its undefined `residual_size` resolved to the evident max(0, .) clamp, and the request's
+        partly filled last page returned too: the reference's floor at :428-431 leaks it)."""
         order = sorted(range(len(self.reqs)),
                        key=lambda i: (len(self.reqs[i].output_ids), -len(self.reqs[i].origin_input_ids)), reverse=True)
         lens = self._lens_host()
@@ -319,7 +337,7 @@ class Batch:
             idx = order.pop()
             req = self.reqs[idx]
             retracted.append(req)
-            ppns = self.page_manager.page_table[req.page_table_id, len(req.prefix_ppns): lens[idx] // ps]
+            ppns = self.page_manager.page_table[req.page_table_id, len(req.prefix_ppns): -(-lens[idx] // ps)]
             self.kvcache._free_pages(ppns.tolist())
             self.page_manager.free([req.page_table_id])
             if self.tree_cache is not None:

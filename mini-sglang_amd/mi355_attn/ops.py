@@ -67,7 +67,7 @@ def prefill_prepare(page_table: torch.Tensor, plan: torch.Tensor, pages: torch.T
     positions = torch.empty(T, dtype=torch.int64, device=dev)
     row_of_token = torch.empty(T, dtype=torch.int64, device=dev)
     loc = torch.empty(T, dtype=torch.int64, device=dev)
-    check(lib.m355_prefill_prepare(page_table.data_ptr(), page_table.stride(0), plan.data_ptr(), pages.data_ptr(),
+    check(lib.m355_prefill_prepare(page_table.data_ptr(), page_table.stride(0), page_table.shape[1], plan.data_ptr(), pages.data_ptr(),
                                    cu_q.data_ptr(), B, page_size, positions.data_ptr(), row_of_token.data_ptr(),
                                    loc.data_ptr(), current_stream()), "m355_prefill_prepare")
     return positions, row_of_token, loc
@@ -84,7 +84,7 @@ def decode_prepare(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: torch
     assert seq_lens.is_contiguous() and rows.is_contiguous()
     B = seq_lens.numel()
     trio = torch.empty((3, B), dtype=torch.int64, device=seq_lens.device)     # new seq_lens | positions | loc
-    check(lib.m355_decode_prepare(page_table.data_ptr(), page_table.stride(0), rows.data_ptr(), seq_lens.data_ptr(),
+    check(lib.m355_decode_prepare(page_table.data_ptr(), page_table.stride(0), page_table.shape[1], rows.data_ptr(), seq_lens.data_ptr(),
                                   trio[0].data_ptr(), new_pages.data_ptr(), B, page_size, trio[1].data_ptr(),
                                   trio[2].data_ptr(), current_stream()), "m355_decode_prepare")
     return trio[0], trio[1], trio[2]
@@ -151,7 +151,7 @@ def decode_prepare_ring(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: 
             assert t.dtype == torch.int64 and t.numel() == B and t.is_contiguous()
     else:
         trio = torch.empty((3, B), dtype=torch.int64, device=seq_lens.device)     # new seq_lens | positions | loc
-    check(lib.m355_decode_prepare_ring(page_table.data_ptr(), page_table.stride(0), rows.data_ptr(), seq_lens.data_ptr(),
+    check(lib.m355_decode_prepare_ring(page_table.data_ptr(), page_table.stride(0), page_table.shape[1], rows.data_ptr(), seq_lens.data_ptr(),
                                        trio[0].data_ptr(), ring.ring.data_ptr(), ring.state.data_ptr(), ring.capacity,
                                        B, page_size, trio[1].data_ptr(), trio[2].data_ptr(), current_stream()),
           "m355_decode_prepare_ring")

@@ -5,7 +5,11 @@ Host-only on purpose: the tree is pointer chasing over a few hundred nodes, and 
 consumed by the host planner (mi355_attn.batch.plan_prefill).  Unlike the reference, node values are Python
 int lists rather than device int32 tensors, so matching never launches a kernel or syncs; the LRU stamp is
 a strictly increasing counter (ties in `time.time()` made the reference's eviction order arbitrary).
-The walk after a node split is kept exactly as the reference has it (see `_match_walk`).
+One deliberate difference in results: after `match_prefix` splits a node the walk STOPS (the key is exhausted at the
+split point).  The reference goes on from the new upper node without consuming the key (:263-267), which with a repeated
+pattern ("abab" cached, "abc" queried at page_size 1) descends into the split-off tail and returns pages of tokens
+that were never asked for - more pages than the key has.  `reference_split_walk=True` restores that walk; only the
+parity tests against the reference's own traces use it.
 """
 from __future__ import annotations
 
@@ -36,10 +40,11 @@ class TreeNode:
 
 
 class PagedRadixCache:
-    def __init__(self, page_manager, kvcache, page_size: Optional[int] = None):
+    def __init__(self, page_manager, kvcache, page_size: Optional[int] = None, reference_split_walk: bool = False):
         self.page_manager = page_manager
         self.kvcache = kvcache
         self.page_size = page_size if page_size is not None else page_manager.page_size
+        self.reference_split_walk = bool(reference_split_walk)
         self.reset()
 
     # ---- keys (radix_cache.py:52-70, 85-90)
@@ -186,12 +191,14 @@ class PagedRadixCache:
             child.touch()
             n = self._match_len(child.key, key)
             if n < len(child.key):
-                # As in the reference (:263-267): after a split the walk goes on from the new upper node WITHOUT
-                # consuming the key, so `ck` is looked up among that node's children next.  It normally misses
-                # (walk ends); a repeated pattern ("abab" cached, "abc" queried at page_size 1) makes it descend
-                # into the split-off tail and over-report.  Parity with the reference wins over tidiness here.
+                # The match ends inside this child: split it there and stop.  (The reference, :263-267, goes on from
+                # the new upper node WITHOUT consuming the key, so `ck` is looked up among that node's children next;
+                # a repeated pattern makes it descend into the split-off tail and over-report.  Kept behind
+                # reference_split_walk for the parity tests.)
                 node = self._split(child, n)
                 chunks.append(node.value)
+                if not self.reference_split_walk:
+                    break
             else:
                 chunks.append(child.value)
                 node = child
@@ -271,6 +278,7 @@ def _radix_lib():
         for name, res, args in (
                 ("m355r_version", ctypes.c_int, []),
                 ("m355r_create", p, [ctypes.c_int32]), ("m355r_destroy", None, [p]), ("m355r_reset", None, [p]),
+                ("m355r_set_reference_walk", None, [p, ctypes.c_int32]),
                 ("m355r_match_prefix", i64, [p, p, i64, p, i64, p]),
                 ("m355r_last_match", i64, [p, p, i64]),
                 ("m355r_insert", i64, [p, p, i64, p, i64]),
@@ -288,13 +296,14 @@ class NativeRadixCache(PagedRadixCache):
     """PagedRadixCache with the tree in native code.  Nodes are opaque integer handles (`req.last_node` holds one);
     the request life-cycle methods are inherited and call the primitives below."""
 
-    def __init__(self, page_manager, kvcache, page_size: Optional[int] = None):
+    def __init__(self, page_manager, kvcache, page_size: Optional[int] = None, reference_split_walk: bool = False):
         import numpy as np
         self._np = np
         self._lib = _radix_lib()
         ps = page_size if page_size is not None else page_manager.page_size
         self._tree = self._lib.m355r_create(int(ps))
-        super().__init__(page_manager, kvcache, page_size)
+        self._lib.m355r_set_reference_walk(self._tree, int(bool(reference_split_walk)))
+        super().__init__(page_manager, kvcache, page_size, reference_split_walk)
 
     def __del__(self):
         tree, self._tree = getattr(self, "_tree", None), None
@@ -316,7 +325,7 @@ class NativeRadixCache(PagedRadixCache):
         out = np.empty(max(cap, 1), dtype=np.int32)
         node = ctypes.c_int64(0)
         n = self._lib.m355r_match_prefix(self._tree, k.ctypes.data, k.size, out.ctypes.data, out.size, ctypes.byref(node))
-        if n > out.size:      # the reference's walk after a split can report more pages than the key has (see _match_walk)
+        if n > out.size:      # only with reference_split_walk: that walk can report more pages than the key has
             out = np.empty(n, dtype=np.int32)
             self._lib.m355r_last_match(self._tree, out.ctypes.data, out.size)
         return out[:n].tolist(), int(node.value)

@@ -70,6 +70,9 @@ FLOW_CASES = [
     ("ps16_8b", 16, (32, 8, 128), [21, 24], [16, 7], 1),
     ("ps16_70b_tp8", 16, (8, 1, 128), [70, 33, 18], [64, 1, 17], 2),
     ("ps1_8b_tp2", 1, (16, 4, 128), [12, 30], [5, 11], 2),
+    # BASELINE.json configs[0]: Llama-3.2-1B, page_size 1, batch 1, 128-token prompt (cut 4 like
+    # bench_one_batch.py:147-188), 16 decode steps
+    ("ps1_1b", 1, (32, 8, 64), [128], [4], 16),
 ]
 
 
@@ -187,8 +190,10 @@ def run_flow(name, ps, heads, lens, cuts, steps, dtype):
     return out
 
 
-def gen_flows():
+def gen_flows(only=None):
     for name, ps, heads, lens, cuts, steps in FLOW_CASES:
+        if only and name not in only:
+            continue
         a = run_flow(name, ps, heads, lens, cuts, steps, torch.bfloat16)
         b = run_flow(name, ps, heads, lens, cuts, steps, torch.float32)
         merged = dict(a)
@@ -318,5 +323,8 @@ def gen_radix():
 # --------------------------------------------------------------------------------------------
 
 if __name__ == "__main__":
-    gen_flows()
-    gen_radix()
+    # no arguments: everything; otherwise only the named flow cases (the others' files are left as they are)
+    only = set(sys.argv[1:])
+    gen_flows(only)
+    if not only:
+        gen_radix()

@@ -1,0 +1,391 @@
+"""GPU parity at BASELINE.json's own workloads and through the objects the reference hands a backend.
+
+  cfg1  Llama-3.2-1B shape, page_size 1, batch 1, 128-token prompt + 16 decode steps (also the golden flow ps1_1b)
+  cfg5  Llama-3-70B / TP8 per-rank shape (8, 1, 128), every request 32 768 tokens, B in {1, 8}
+  the reference's own Batch / KVCache shapes (no host mirrors, separate pool tensors per layer)
+  PagedRadixCache -> prefix_ppns -> shared physical pages -> HIP prefill
+  the device page ring at a batch larger than one round of its kernel
+
+Bars as in test_gpu_parity.py: integers and pools bit-exact, attention within BF16_ATOL / BF16_RTOL of the oracle."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from flow_util import BF16_ATOL, BF16_RTOL, GOLDEN, FlowReplay
+from synth import synth
+from oracle import attention_ref as A
+from oracle import memory_ref as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mods():
+    import mi355_attn
+    from mi355_attn import ops
+    return mi355_attn, ops
+
+
+def _runner(m, ps, kv, pm):
+    return SimpleNamespace(device=DEV, page_size=ps, kvcache=kv, page_manager=pm)
+
+
+# ------------------------------------------------------------------------------------------------
+# cfg1
+# ------------------------------------------------------------------------------------------------
+def test_cfg1_1b_ps1_prompt128_then_16_decode_steps():
+    """configs[0] on the HIP path: one 128-token prompt prefilled with no prefix at page_size 1 (every token its own
+    page), then 16 decode steps, through Batch + MI355AttnBackend; oracle = the fp64 formula on the oracle's pools."""
+    m, ops = _mods()
+    Hq, Hkv, D, ps, L0, steps = 32, 8, 64, 1, 128, 16
+    n_pages = L0 + steps + 8
+    perm = torch.randperm(n_pages, generator=torch.Generator().manual_seed(3)).tolist()     # scattered pages
+    kv = m.KVCache(size=n_pages, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=1, device=DEV,
+                   device_free_list=True)
+    kv.set_free_pages(perm)
+    pm = m.PageManager(page_size=ps, max_req_num=8, max_context_len=L0 + steps + 4, device=DEV)
+    backend = m.MI355AttnBackend(_runner(m, ps, kv, pm))
+    layer = m.Attention(layer_id=0, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=D ** -0.5)
+    pool = M.RefPagePool(n_pages, ps)
+    pool.free_pages = list(perm)
+    pt = M.RefPageTable(ps, 8, L0 + steps + 4)
+    rk = torch.zeros((n_pages, Hkv, D), dtype=torch.bfloat16)
+    rv = torch.zeros_like(rk)
+
+    req = m.Req(0, list(range(L0)))                       # input_ids = arange(128)
+    req.fill_ids = list(req.origin_input_ids)
+    batch = m.Batch([req], page_manager=pm, kvcache=kv, device=DEV)
+    batch.prepare_for_prefill()
+    meta = M.prepare_for_prefill_ref([M.RefReq(fill_ids=list(range(L0)))], pool, pt)
+    for step in range(-1, steps):
+        if step >= 0:
+            batch.output_ids = torch.tensor([1000 + step], dtype=torch.int64, device=DEV)
+            batch.prepare_for_decode()
+            meta = M.prepare_for_decode_ref(meta, [1000 + step], pool, pt)
+        for f in ("seq_lens", "positions", "out_cache_loc", "page_table_ids"):
+            assert np.array_equal(getattr(batch, f).cpu().numpy(), getattr(meta, f)), (step, f)
+        T = int(meta.input_ids.shape[0])
+        qkv = synth((T, (Hq + 2 * Hkv) * D), 50 + step, amp=2.0, dtype=torch.bfloat16)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        A.write_kv_ref(rk, rv, torch.from_numpy(meta.out_cache_loc), k.view(-1, Hkv, D), v.view(-1, Hkv, D))
+        ref = A.paged_attn_f64(q.reshape(T, Hq, D), rk, rv, torch.from_numpy(pt.table), torch.from_numpy(meta.page_table_ids),
+                               torch.from_numpy(meta.seq_lens), torch.from_numpy(meta.prefix_lens) if step < 0 else None,
+                               ps).reshape(T, Hq * D).float().numpy()
+        dq, dk, dv = qkv.to(DEV).split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        backend.init_forward_metadata(batch)
+        o = backend.forward(dq, dk, dv, layer, batch)
+        torch.cuda.synchronize()
+        kp, vp = kv.get_kv_cache(0)
+        assert torch.equal(kp.cpu(), rk) and torch.equal(vp.cpu(), rv), step
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"step {step}")
+
+
+# ------------------------------------------------------------------------------------------------
+# cfg5
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 8])
+def test_cfg5_70b_tp8_32k_decode(B):
+    """configs[4] per rank: (Hq, Hkv, D) = (8, 1, 128), page_size 16, every request 32 768 tokens (the new one
+    included), planned decode with the KV store fused in; requests are cut into many pieces here (the wide merge at
+    B = 1).  Oracle: paged_attn_f64 on the CPU copy of the pools after the write."""
+    m, ops = _mods()
+    Hq, Hkv, D, ps, L = 8, 1, 128, 16, 32768
+    lens = [L] * B
+    npages = B * (L // ps)
+    perm = torch.randperm(npages, generator=torch.Generator().manual_seed(B)).to(torch.int32)
+    table = perm.view(B, L // ps).contiguous()
+    g = torch.Generator().manual_seed(100 + B)
+    kp = torch.randn((npages * ps, Hkv, D), generator=g).to(torch.bfloat16)
+    vp = torch.randn((npages * ps, Hkv, D), generator=g).to(torch.bfloat16)
+    qkv = (torch.randn((B, (Hq + 2 * Hkv) * D), generator=g) * 2).to(torch.bfloat16)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    rows = torch.arange(B)
+    pos = np.asarray(lens, dtype=np.int64) - 1
+    loc = torch.from_numpy(M.out_cache_loc_ref(table.numpy(), rows.numpy(), pos, ps))
+    rk, rv = kp.clone(), vp.clone()
+    A.write_kv_ref(rk, rv, loc, k.reshape(B, Hkv, D), v.reshape(B, Hkv, D))
+    ref = A.paged_attn_f64(q.reshape(B, Hq, D), rk, rv, table, rows, torch.tensor(lens), None, ps).reshape(B, Hq * D).float().numpy()
+
+    dqkv = qkv.to(DEV)
+    dq, dk, dv = dqkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    dkp, dvp, dt = kp.to(DEV), vp.to(DEV), table.to(DEV)
+    dr, dl = rows.to(DEV), torch.tensor(lens, device=DEV)
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    o = ops.decode_attn_planned(dq, dkp, dvp, plan, Hq, k_new=dk, v_new=dv)
+    torch.cuda.synchronize()
+    assert torch.equal(dkp.cpu(), rk) and torch.equal(dvp.cpu(), rv)
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    # the plan-free form of the same pools gives the same answer
+    o2 = ops.decode_attn_planned(dq, dkp, dvp, plan, Hq)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o2.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own objects
+# ------------------------------------------------------------------------------------------------
+class _RefShapedKVCache:
+    """memory/kvcache.py:24-35, 81-85: one separate tensor per layer for K and for V, nothing else the backend may use
+    except head_num / head_dim / page_size."""
+
+    def __init__(self, rows, Hkv, D, layers, ps):
+        self.page_size, self.head_num, self.head_dim, self.layer_num = ps, Hkv, D, layers
+        self.page_num = rows // ps
+        self.k_cache = [torch.zeros((rows, Hkv, D), dtype=torch.bfloat16, device=DEV) for _ in range(layers)]
+        self.v_cache = [torch.zeros((rows, Hkv, D), dtype=torch.bfloat16, device=DEV) for _ in range(layers)]
+
+    def get_kv_cache(self, layer_id):
+        return self.k_cache[layer_id], self.v_cache[layer_id]
+
+
+class _RefMode:
+    def __init__(self, decode):
+        self._d = decode
+
+    def is_decode(self):
+        return self._d
+
+    def is_prefill(self):
+        return not self._d
+
+
+@pytest.mark.parametrize("name", ["ps16_1b", "ps1_8b_tp2", "ps4_tiny", "ps16_70b_tp8"])
+def test_backend_with_reference_shaped_batch(name):
+    """What INTEGRATION.md promises: the backend driven by objects that carry only what the reference's Batch,
+    KVCache and PageManager carry (engine/batch.py:192-231, memory/kvcache.py:24-35): device tensors mode / seq_lens /
+    prefix_lens / page_table_ids / out_cache_loc, no seq_lens_host, no cu_q, k and v passed, one pool tensor per layer,
+    keyword arguments as layers/attention.py:30-36 passes them.  A golden flow is replayed through it, with the
+    reference's own metadata values; pools bit-exact, outputs within tolerance, on a layer other than 0."""
+    m, ops = _mods()
+    fr = FlowReplay(os.path.join(GOLDEN, f"flow_{name}.npz"), torch.bfloat16)
+    ps, Hq, Hkv, D = fr.ps, fr.Hq, fr.Hkv, fr.D
+    kv = _RefShapedKVCache(fr.S_pages * ps, Hkv, D, layers=2, ps=ps)
+    pm = SimpleNamespace(page_size=ps, page_table=torch.zeros((fr.max_req, fr.ctx // ps), dtype=torch.int32, device=DEV))
+    backend = m.MI355AttnBackend(SimpleNamespace(device=DEV, page_size=ps))            # torch_native_backend.py:16-19 reads only these
+    layer = SimpleNamespace(layer_id=1, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=None)
+    for ph in fr.phases():
+        pm.page_table.copy_(torch.from_numpy(ph.table))               # as Batch.prepare_* left it
+        batch = SimpleNamespace(
+            mode=_RefMode(ph.decode), reqs=[None] * fr.n, page_manager=pm, page_size=ps, kvcache=kv, device=DEV,
+            seq_lens=torch.from_numpy(fr.golden(ph.tag, "seq_lens")).to(DEV),
+            prefix_lens=torch.from_numpy(fr.golden(ph.tag, "prefix_lens")).to(DEV),
+            page_table_ids=torch.from_numpy(fr.golden(ph.tag, "page_table_ids")).to(DEV),
+            out_cache_loc=torch.from_numpy(fr.golden(ph.tag, "out_cache_loc")).to(DEV),
+            positions=torch.from_numpy(fr.golden(ph.tag, "positions")).to(DEV))
+        qkv = ph.qkv.to(DEV)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        backend.init_forward_metadata(batch)                          # model_runner.py:194
+        batch.attn_backend = backend                                  # :195
+        o = batch.attn_backend.forward(q=q, k=k, v=v, layer=layer, batch=batch)
+        torch.cuda.synchronize()
+        assert o.shape == (q.shape[0], Hq * D) and o.dtype == torch.bfloat16 and o.data_ptr() != q.data_ptr()
+        assert torch.equal(kv.k_cache[1].cpu(), ph.k_pool) and torch.equal(kv.v_cache[1].cpu(), ph.v_pool), ph.tag
+        assert not kv.k_cache[0].any() and not kv.v_cache[0].any()   # the other layer's pools are untouched
+        rows_, ref = fr.golden_o_f32(ph.tag)
+        np.testing.assert_allclose(o.float().cpu().numpy()[rows_], ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=ph.tag)
+
+
+def test_decode_steps_without_the_metadata_hook():
+    """two consecutive decode forwards with NO init_forward_metadata in between (legal against the
+    torch-native backend, whose hook is a no-op).  The per-forward plan must follow the batch: the second step attends
+    the second step's token and writes the second step's slots."""
+    m, ops = _mods()
+    fr = FlowReplay(os.path.join(GOLDEN, "flow_ps4_tiny.npz"), torch.bfloat16)
+    ps, Hq, Hkv, D = fr.ps, fr.Hq, fr.Hkv, fr.D
+    kv = m.KVCache(size=fr.S_pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=2, device=DEV)
+    pm = m.PageManager(page_size=ps, max_req_num=fr.max_req, max_context_len=fr.ctx, device=DEV)
+    backend = m.MI355AttnBackend(_runner(m, ps, kv, pm))
+    layers = [m.Attention(layer_id=i, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=D ** -0.5) for i in range(2)]
+    reqs, batch = None, None
+    for ph in fr.phases():
+        if ph.tag == "p1":
+            reqs = [m.Req(i, fr.ids[i][: fr.cuts[i]]) for i in range(fr.n)]
+            for r in reqs:
+                r.fill_ids = list(r.origin_input_ids)
+            batch = m.Batch(reqs, page_manager=pm, kvcache=kv, device=DEV)
+            batch.prepare_for_prefill()
+        elif ph.tag == "p2":
+            for i, r in enumerate(reqs):
+                r.fill_ids = list(fr.ids[i])
+                r.prefix_ppns = pm.page_table[i, : fr.cuts[i] // ps].tolist()
+            batch = m.Batch(reqs, page_manager=pm, kvcache=kv, device=DEV)
+            batch.prepare_for_prefill()
+        else:
+            batch.output_ids = torch.tensor(ph.next_ids, dtype=torch.int64, device=DEV)
+            batch.prepare_for_decode()
+        qkv = ph.qkv.to(DEV)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        if not ph.decode or ph.tag == "d0":
+            backend.init_forward_metadata(batch)          # prefills and the first decode step: hook called; later: not
+        batch.attn_backend = backend
+        outs = [layer(q, k, v, batch) for layer in layers]            # two layers per forward
+        torch.cuda.synchronize()
+        for li, o in enumerate(outs):
+            kp, vp = kv.get_kv_cache(li)
+            assert torch.equal(kp.cpu(), ph.k_pool) and torch.equal(vp.cpu(), ph.v_pool), (ph.tag, li)
+            np.testing.assert_allclose(o.float().cpu().numpy(), ph.out.float().numpy(), rtol=BF16_RTOL, atol=BF16_ATOL,
+                                       err_msg=f"{ph.tag} layer {li}")
+
+
+# ------------------------------------------------------------------------------------------------
+# radix cache -> shared physical pages -> prefill
+# ------------------------------------------------------------------------------------------------
+def _token_kv(ids, pos, Hq, Hkv, D, salt):
+    """Deterministic q/k/v rows for (token id, position): what a model would produce - equal tokens at equal positions
+    give equal K/V, so a shared cached page holds exactly what a request that re-computed it would have written."""
+    rows = []
+    for t, p in zip(ids, pos):
+        rows.append(synth((1, (Hq + 2 * Hkv) * D), 7919 * int(t) + 31 * int(p) + salt, amp=2.0, dtype=torch.bfloat16))
+    return torch.cat(rows, 0)
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["python_tree", "native_tree"])
+def test_radix_hits_feed_shared_pages_to_prefill(native):
+    """north_star: "ragged prefill over RadixCache-hit prefixes".  The scheduler's sequence (engine/scheduler.py:295-297,
+    415-436; engine/batch.py:128-132) on the golden trace ps16_shared_prefix: match_prefix -> prefix_ppns ->
+    prepare_for_prefill -> HIP KV store + prefill over pages that EARLIER requests wrote -> cache_unfinished_req.
+    Page rows, prefixes and slots must be the reference's (radix_traces.json); attention is checked against the oracle
+    on CPU pools that only ever receive each request's NEW tokens.  Then two fresh requests that share the cached
+    prefix go through ONE batch (the same physical pages in two page-table rows of one launch)."""
+    m, ops = _mods()
+    from mi355_attn.radix_cache import NativeRadixCache, PagedRadixCache
+    with open(os.path.join(GOLDEN, "radix_traces.json")) as f:
+        tr = json.load(f)["ps16_shared_prefix"]
+    ps, prompts = tr["ps"], tr["prompts"]
+    Hq, Hkv, D = 8, 2, 128
+    ctx = 256
+    kv = m.KVCache(size=tr["n_pages"] * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=1, device=DEV)
+    pm = m.PageManager(page_size=ps, max_req_num=len(prompts) + 3, max_context_len=ctx, device=DEV)
+    tree = (NativeRadixCache if native else PagedRadixCache)(pm, kv, reference_split_walk=True)
+    backend = m.MI355AttnBackend(_runner(m, ps, kv, pm))
+    layer = m.Attention(layer_id=0, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=D ** -0.5)
+    rk = torch.zeros((tr["n_pages"] * ps, Hkv, D), dtype=torch.bfloat16)
+    rv = torch.zeros_like(rk)
+    golden = [s for s in tr["steps"] if s["op"] == "prefill"]
+
+    def serve(reqs):
+        for r in reqs:
+            r.init_next_round_input(tree)                              # match_prefix (batch.py:128-132)
+        batch = m.Batch(reqs, page_manager=pm, kvcache=kv, tree_cache=tree, device=DEV)
+        batch.prepare_for_prefill()
+        pre = [len(r.prefix_ppns) * ps for r in reqs]
+        ids = [r.fill_ids[p:] for r, p in zip(reqs, pre)]
+        qkv = torch.cat([_token_kv(i_, range(p, p + len(i_)), Hq, Hkv, D, 5) for i_, p in zip(ids, pre)], 0)
+        loc = batch.out_cache_loc.cpu()
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        A.write_kv_ref(rk, rv, loc, k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D))          # only the NEW tokens
+        table = pm.page_table.cpu()
+        ref = A.paged_attn_f64(q.reshape(-1, Hq, D), rk, rv, table, batch.page_table_ids.cpu(), batch.seq_lens.cpu(),
+                               batch.prefix_lens.cpu(), ps).reshape(-1, Hq * D).float().numpy()
+        dq, dk, dv = qkv.to(DEV).split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        backend.init_forward_metadata(batch)
+        o = backend.forward(dq, dk, dv, layer, batch)
+        torch.cuda.synchronize()
+        kp, vp = kv.get_kv_cache(0)
+        assert torch.equal(kp.cpu(), rk) and torch.equal(vp.cpu(), rv)
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+        return batch, pre
+
+    reqs = []
+    for i, p in enumerate(prompts):
+        r = m.Req(i, list(p), m.SamplingParams(max_new_tokens=4))
+        batch, pre = serve([r])
+        g = golden[i]
+        used = -(-len(p) // ps)
+        assert [int(x) for x in r.prefix_ppns] == g["prefix_ppns"] and pre[0] == g["prefix_len"]
+        assert pm.page_table[r.page_table_id, :used].tolist() == g["page_row"]
+        assert batch.out_cache_loc.tolist() == g["out_cache_loc"]
+        r.output_ids.append(7000 + i)
+        tree.cache_unfinished_req(r)
+        reqs.append(r)
+    assert golden[1]["prefix_len"] > 0 and golden[2]["prefix_len"] > 0         # the trace does hit the cache
+    # two new requests over the cached 48-token system prompt, in one batch: both rows start with the SAME pages
+    a = m.Req(10, list(range(48)) + [900 + j for j in range(37)], m.SamplingParams(max_new_tokens=4))
+    b = m.Req(11, list(range(48)) + [950 + j for j in range(5)], m.SamplingParams(max_new_tokens=4))
+    batch, pre = serve([a, b])
+    assert pre == [48, 48]
+    ra, rb = pm.page_table[a.page_table_id, :3].tolist(), pm.page_table[b.page_table_id, :3].tolist()
+    assert ra == rb == [int(x) for x in reqs[0].prefix_ppns[:3]]
+
+
+# ------------------------------------------------------------------------------------------------
+# metadata kernels at sizes and edges the flows do not reach
+# ------------------------------------------------------------------------------------------------
+def test_decode_prepare_ring_more_than_one_round():
+    """B = 1500 > the 1024 requests one round of decode_prepare_ring_kernel handles: the pages taken in round 1 must
+    carry over into round 2 (engine/batch.py:325-343 + memory/kvcache.py:49-56 in batch order)."""
+    m, ops = _mods()
+    rng = np.random.default_rng(8)
+    for ps in (1, 4, 16):
+        B = 1500
+        W = 12
+        lens = rng.integers(1, (W - 1) * ps, size=B).astype(np.int64)
+        lens[rng.integers(0, B, size=400)] = rng.integers(1, W - 1, size=400) * ps          # many page starts
+        n_need = int((lens % ps == 0).sum())
+        cap = 4096
+        ring_pages = rng.permutation(cap)[: n_need + 50].astype(np.int32)
+        table = rng.integers(0, 1 << 20, size=(B + 5, W), dtype=np.int32)
+        rows = rng.permutation(B + 5)[:B].astype(np.int64)
+        # host statement: the vectorised plan + the oracle's slot formula
+        want_table = table.copy()
+        new_pages = np.full(B, -1, dtype=np.int32)
+        new_pages[lens % ps == 0] = ring_pages[:n_need]
+        pos = lens.copy()
+        for b in np.nonzero(new_pages >= 0)[0]:
+            want_table[rows[b], pos[b] // ps] = new_pages[b]
+        want_loc = M.out_cache_loc_ref(want_table, rows, pos, ps)
+        ring = ops.PageRing(cap, DEV)
+        ring.load(ring_pages.tolist())
+        dt = torch.from_numpy(table).to(DEV)
+        new_lens, positions, loc = ops.decode_prepare_ring(dt, torch.from_numpy(rows).to(DEV), torch.from_numpy(lens).to(DEV), ring, ps)
+        torch.cuda.synchronize()
+        assert np.array_equal(new_lens.cpu().numpy(), lens + 1)
+        assert np.array_equal(positions.cpu().numpy(), pos)
+        assert np.array_equal(loc.cpu().numpy(), want_loc), ps
+        assert np.array_equal(dt.cpu().numpy(), want_table), ps
+        assert ring.snapshot() == ring_pages[n_need:].tolist()
+        # and the host-planned kernel agrees
+        dt2 = torch.from_numpy(table).to(DEV)
+        l2, p2, loc2 = ops.decode_prepare(dt2, torch.from_numpy(rows).to(DEV), torch.from_numpy(lens).to(DEV),
+                                          torch.from_numpy(new_pages).to(DEV), ps)
+        assert torch.equal(loc2, loc) and torch.equal(dt2, dt) and torch.equal(l2, new_lens)
+
+
+def test_page_table_width_is_a_hard_bound():
+    """a request longer than the page table is wide must not reach the next request's row.  The planner
+    refuses it (nothing allocated); the kernels, called directly with such a plan, drop the out-of-range entries and
+    mark the slots -1, which m355_kv_store skips."""
+    m, ops = _mods()
+    ps, W = 4, 3
+    kv = m.KVCache(size=64 * ps, page_size=ps, head_num=1, head_dim=64, dtype=torch.bfloat16, layer_num=1, device=DEV)
+    pm = m.PageManager(page_size=ps, max_req_num=4, max_context_len=W * ps, device=DEV)
+    r = m.Req(0, list(range(W * ps + 1)))
+    r.fill_ids = list(r.origin_input_ids)
+    with pytest.raises(RuntimeError, match="columns"):
+        m.Batch([r], page_manager=pm, kvcache=kv, device=DEV).prepare_for_prefill()
+    assert kv.available_page_num() == 64 and len(pm.free_slots) == 4
+    ok = m.Req(1, list(range(W * ps)))
+    ok.fill_ids = list(ok.origin_input_ids)
+    batch = m.Batch([ok], page_manager=pm, kvcache=kv, device=DEV)
+    batch.prepare_for_prefill()                                       # exactly W pages: fine
+    batch.output_ids = torch.zeros(1, dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError, match="columns"):
+        batch.prepare_for_decode()
+    # the kernels themselves: 2 requests of 4 pages each into a table 3 columns wide
+    table = torch.full((2, W), -7, dtype=torch.int32, device=DEV)
+    plan = torch.tensor([[0, 0, 16, 0], [1, 0, 16, 4], [0, 0, 0, 8]], dtype=torch.int32, device=DEV).reshape(-1)
+    pages = torch.arange(10, 18, dtype=torch.int32, device=DEV)
+    cu_q = torch.tensor([0, 16, 32], dtype=torch.int32, device=DEV)
+    pos, rot, loc = ops.prefill_prepare(table, plan, pages, cu_q, 2, 32, ps)
+    torch.cuda.synchronize()
+    assert table.tolist() == [[10, 11, 12], [14, 15, 16]]
+    loc = loc.cpu().numpy().reshape(2, 16)
+    assert (loc[:, 12:] == -1).all() and loc[0, :12].tolist() == list(range(40, 52)) and loc[1, :12].tolist() == list(range(56, 68))
+    lens = torch.tensor([12, 5], dtype=torch.int64, device=DEV)
+    l2, p2, loc2 = ops.decode_prepare(table, torch.tensor([0, 1], device=DEV), lens, torch.tensor([99, -1], dtype=torch.int32, device=DEV), ps)
+    torch.cuda.synchronize()
+    assert table.tolist() == [[10, 11, 12], [14, 15, 16]] and loc2.tolist() == [-1, 15 * ps + 1]

@@ -38,9 +38,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mi355attn.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r"\b(m355_[a-z0-9_]+)\b", out))
+    exported = set(re.findall(r"\b(m355[a-z]*_[a-z0-9_]+)\b", out))
     assert set(declared) <= exported
-    assert lib.m355_version() == 100
+    assert lib.m355_version() == 200
     assert b"workspace" in lib.m355_strerror(-3)
 
 
@@ -125,6 +125,59 @@ def test_pool_exhaustion_is_an_error_not_a_none():
     assert kv._allocate_pages(3) is None and kv.available_page_num() == 2     # kvcache.py:60-61 behaviour kept
 
 
+def test_planner_refuses_requests_wider_than_the_page_table():
+    """ceil(seq_len / ps) > max_page_num must fail on the host, before any row or page is taken (the
+    reference fails on the row write, memory/page_manager.py:46, :54)."""
+    m = _m()
+    from mi355_attn.batch import plan_decode, plan_prefill
+    ps, W = 4, 3
+    kv = m.KVCache(size=64 * ps, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+    pm = m.PageManager(page_size=ps, max_req_num=4, max_context_len=W * ps, device="cpu")
+    ok, bad = m.Req(0, list(range(W * ps))), m.Req(1, list(range(W * ps + 1)))
+    ok.fill_ids, bad.fill_ids = ok.origin_input_ids, bad.origin_input_ids
+    with pytest.raises(RuntimeError, match="columns"):
+        plan_prefill([ok, bad], pm, kv)
+    assert kv.available_page_num() == 64 and pm.free_slots == [0, 1, 2, 3]          # nothing leaked
+    plan = plan_prefill([ok], pm, kv)
+    assert len(plan.pages) == W
+    with pytest.raises(RuntimeError, match="columns"):
+        plan_decode(plan.seq_lens, kv, pm)
+    assert kv.available_page_num() == 64 - W
+    # a pool that is too small is noticed before the rows are taken, too
+    small = m.KVCache(size=2 * ps, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+    pm2 = m.PageManager(page_size=ps, max_req_num=2, max_context_len=64, device="cpu")
+    r = m.Req(2, list(range(9)))
+    r.fill_ids = r.origin_input_ids
+    with pytest.raises(RuntimeError, match="exhausted"):
+        plan_prefill([r], pm2, small)
+    assert pm2.free_slots == [0, 1] and small.available_page_num() == 2
+
+
+def test_retract_returns_the_partly_filled_last_page():
+    """retract_decode must give back ceil(len / ps) - prefix pages, not floor (engine/batch.py:428-431
+    leaks the last page of every retracted request whose length is not a page multiple)."""
+    m = _m()
+    ps = 4
+    kv = m.KVCache(size=16 * ps, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
+    pm = m.PageManager(page_size=ps, max_req_num=4, max_context_len=64, device="cpu")
+    reqs = [m.Req(i, list(range(n))) for i, n in enumerate((9, 6, 13))]
+    b = m.Batch(reqs, page_manager=pm, kvcache=kv, device="cpu")
+    rows = pm.allocate(3)
+    pages = kv.allocate_pages_prefill([9, 6, 13], [0, 0, 0])
+    for r, row, pg in zip(reqs, rows, pages):
+        r.page_table_id = row
+        pm.write_ppns_prefill(row, pg)
+    b.page_table_ids = torch.tensor(rows)
+    b.seq_lens = torch.tensor([9, 6, 13])
+    b.seq_lens_host = [9, 6, 13]
+    assert kv.available_page_num() == 16 - (3 + 2 + 4)
+    retracted, _ = b.retract_decode(retract_decode_steps=10 ** 6)       # cannot be satisfied: all but one go back
+    assert len(retracted) == 2 and len(b.reqs) == 1
+    kept = -(-b.seq_lens_host[0] // ps)
+    assert kv.available_page_num() == 16 - kept                         # every page of the retracted requests is back
+    assert sorted(pm.free_slots) == sorted(set(range(4)) - {b.reqs[0].page_table_id})
+
+
 def test_vectorised_decode_plan_equals_the_per_request_allocator():
     """plan_decode (one numpy pass) hands out exactly the pages, in exactly the order, of the reference-shaped
     per-request loop allocate_pages_decode (memory/kvcache.py:49-56), for any page size; a short pool raises."""
@@ -168,7 +221,7 @@ def test_radix_cache_trace(name, native):
     ctx = (max(len(p) for p in prompts) + 8) // ps * ps + ps
     kv = m.KVCache(size=tr["n_pages"] * ps, page_size=ps, head_num=1, head_dim=8, dtype=torch.bfloat16, layer_num=1, device="cpu")
     pm = m.PageManager(page_size=ps, max_req_num=len(prompts) + 1, max_context_len=ctx, device="cpu")
-    tree = (NativeRadixCache if native else m.PagedRadixCache)(pm, kv)
+    tree = (NativeRadixCache if native else m.PagedRadixCache)(pm, kv, reference_split_walk=True)   # the reference's traces
     steps = iter(tr["steps"])
 
     def check(op, **extra):
@@ -223,7 +276,9 @@ def test_native_radix_tree_equals_the_python_tree_on_random_traffic():
     rng = np.random.default_rng(3)
     for ps in (1, 2, 4, 16):
         pools = [Pool(), Pool()]
-        trees = [PagedRadixCache(None, pools[0], page_size=ps), NativeRadixCache(None, pools[1], page_size=ps)]
+        ref_walk = bool(ps % 4 == 1 or ps == 2)                     # both walks get random traffic
+        trees = [PagedRadixCache(None, pools[0], page_size=ps, reference_split_walk=ref_walk),
+                 NativeRadixCache(None, pools[1], page_size=ps, reference_split_walk=ref_walk)]
         held = []                                                    # (python node, native handle) pairs that are locked
         next_page = 0
         for step in range(400):
@@ -259,6 +314,39 @@ def test_native_radix_tree_equals_the_python_tree_on_random_traffic():
         trees[0].evict(10 ** 6)
         trees[1].evict(10 ** 6)
         assert pools[0].freed == pools[1].freed
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["python_tree", "native_tree"])
+def test_radix_match_never_returns_more_pages_than_the_key(native):
+    """"abab" cached, "abc" queried at page_size 1.  The reference's walk after the split descends into the
+    split-off tail and returns 4 pages for a 3-token key; the product's walk stops at the split."""
+    from mi355_attn.radix_cache import NativeRadixCache, PagedRadixCache
+    cls = NativeRadixCache if native else PagedRadixCache
+    a, b, c = 11, 22, 33
+    for ref_walk, want in ((False, [100, 101]), (True, [100, 101, 102, 103])):
+        tree = cls(None, None, page_size=1, reference_split_walk=ref_walk)
+        assert tree.insert([a, b, a, b], [100, 101, 102, 103]) == 0
+        ppns, _ = tree.match_prefix([a, b, c])
+        assert ppns == want
+        if not ref_walk:
+            assert len(ppns) <= 3
+    rng = np.random.default_rng(0)
+    for ps in (1, 2, 4):                                            # random traffic: a match is always a true prefix
+        tree = cls(None, None, page_size=ps)
+        stored, nxt = {}, 0
+        for _ in range(300):
+            key = [int(x) for x in rng.integers(0, 2, size=int(rng.integers(0, 7 * ps)))]
+            if rng.integers(0, 2):
+                pages = list(range(nxt, nxt + len(key) // ps))
+                nxt += len(pages)
+                got = tree.insert(key, pages) // ps
+                for i in range(got, len(pages)):
+                    stored[tuple(key[: (i + 1) * ps])] = pages[i]
+            else:
+                ppns, _ = tree.match_prefix(key)
+                assert len(ppns) * ps <= len(key)
+                for i, pg in enumerate(ppns):
+                    assert stored[tuple(key[: (i + 1) * ps])] == pg
 
 
 def test_native_radix_library_exports_its_header():
