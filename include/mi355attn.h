@@ -33,7 +33,8 @@ enum {
     M355_ERR_INVALID_ARG = -1, /* null pointer, negative size, misaligned pointer/stride        */
     M355_ERR_UNSUPPORTED = -2, /* head_dim / group size / dtype this build has no kernel for    */
     M355_ERR_WORKSPACE = -3,   /* workspace missing or smaller than m355_decode_workspace_bytes */
-    M355_ERR_LAUNCH = -4       /* hipGetLastError() after the launch was not hipSuccess         */
+    M355_ERR_LAUNCH = -4,      /* hipGetLastError() after the launch was not hipSuccess         */
+    M355_ERR_SCRATCH_LIMIT = -5 /* the call needs more than M355_STATIC_SCRATCH_BYTES of scratch */
 };
 
 /* Element type of q / K / V / out.  Attention: bf16 everywhere; IEEE half (Llama-2-style fp16 checkpoints, the dtype
@@ -164,6 +165,22 @@ int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const vo
                                    const void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                    int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
                                    int64_t workspace_bytes, int32_t dtype, void *stream);
+
+/* m355_decode_store_attn_planned for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its backends allocate freely through
+ * torch); same arguments minus the workspace, same pools and the same output bit for bit.  The fp32 partials live in a
+ * device array inside the library instead - M355_STATIC_SCRATCH_BYTES per GPU the library has run on, held until the
+ * process ends - and the call allocates and frees nothing.  A batch whose
+ * m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity) exceeds that limit is refused with
+ * M355_ERR_SCRATCH_LIMIT (nothing is launched); use the workspace form for it.  Every call on one GPU shares that
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race - order them.  The first call on a
+ * device looks the array's address up (hipGetSymbolAddress): make it outside graph capture. */
+#define M355_STATIC_SCRATCH_BYTES (8 * 1024 * 1024)
+int m355_decode_store_attn_planned_static(const void *q, int64_t q_row_stride, const void *k_new, int64_t k_row_stride,
+                                          const void *v_new, int64_t v_row_stride, void *k_pool, void *v_pool,
+                                          const void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                          int32_t Hkv, int32_t D, float scale, int64_t token_capacity, int32_t dtype,
+                                          void *stream);
 
 /* Ragged prefill ("extend") attention over cached prefixes.  Replaces
  * TorchNativeAttnBackend.forward_extend / _run_sdpa_forward_extend

@@ -21,9 +21,17 @@
 // Algorithmic bytes are those of decode_attn.hip; the plan adds 4 bytes per token per forward.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "stream_plan.h"
 
 namespace m355 {
+
+// Scratch of the allocation-free entry point (m355_decode_store_attn_planned_static): the fp32 partials workspace as a
+// file-scope device array.  Every GPU the library runs on holds its own copy at its own address until the process
+// ends; host code never uses the array's name as an address - only the per-device pointer that
+// hipGetSymbolAddress returned (static_scratch() below).
+static __device__ __align__(256) unsigned char scratch[M355_STATIC_SCRATCH_BYTES];
 
 static unsigned long long* g_stream_stamps = nullptr;   // host copy of the dev-only stamp buffer pointer
 
@@ -663,6 +671,42 @@ extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, con
                                         int64_t workspace_bytes, int32_t dtype, void* stream) {
     return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     token_capacity, workspace, workspace_bytes, dtype, stream, nullptr, 0, nullptr, 0);
+}
+
+// The device address of `scratch` on the CURRENT device, looked up once per device with that device current.
+static void* static_scratch() {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static void* ptrs[kMaxDevices] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(m355::scratch)) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+        ptrs[dev] = p;
+    }
+    return ptrs[dev];
+}
+
+extern "C" int m355_decode_store_attn_planned_static(const void* q, int64_t q_row_stride, const void* k_new,
+                                                     int64_t k_row_stride, const void* v_new, int64_t v_row_stride,
+                                                     void* k_pool, void* v_pool, const void* plan, void* out,
+                                                     int64_t o_row_stride, int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                                                     float scale, int64_t token_capacity, int32_t dtype, void* stream) {
+    if (B == 0) return M355_OK;
+    if (!k_new || !v_new || k_row_stride < (int64_t)Hkv * D || v_row_stride < (int64_t)Hkv * D || (k_row_stride % 8) ||
+        (v_row_stride % 8) || (((uintptr_t)k_new | (uintptr_t)v_new) & 15))
+        return M355_ERR_INVALID_ARG;
+    if (B < 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return M355_ERR_INVALID_ARG;
+    if (m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity) > (int64_t)M355_STATIC_SCRATCH_BYTES)
+        return M355_ERR_SCRATCH_LIMIT;
+    void* ws = static_scratch();
+    if (!ws) return M355_ERR_LAUNCH;
+    // Nothing in the scratch has to start at zero: every partial the merge reads is written by this same call.
+    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
+                                    token_capacity, ws, (int64_t)M355_STATIC_SCRATCH_BYTES, dtype, stream, k_new,
+                                    k_row_stride, v_new, v_row_stride);
 }
 
 extern "C" int m355_decode_store_attn_planned(const void* q, int64_t q_row_stride, const void* k_new, int64_t k_row_stride,

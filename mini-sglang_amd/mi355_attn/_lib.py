@@ -43,6 +43,9 @@ SIGNATURES = {
     "m355_decode_store_attn_planned": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_float,
                                                  c_int64, c_void_p, c_int64, c_int32, c_void_p]),
+    "m355_decode_store_attn_planned_static": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                                        c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                                        c_int32, c_float, c_int64, c_int32, c_void_p]),
     "m355_prefill_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "m355_prefill_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,

@@ -223,13 +223,18 @@ def decode_planned_workspace_bytes(B: int, Hq: int, Hkv: int, D: int, token_capa
     return int(_lib.load().m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity))
 
 
+STATIC_SCRATCH_BYTES = 8 * 1024 * 1024        # M355_STATIC_SCRATCH_BYTES (include/mi355attn.h)
+
+
 def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, plan: DecodePlan,
                         num_heads: int, scale: float | None = None, workspace: torch.Tensor | None = None,
                         out: torch.Tensor | None = None, k_new: torch.Tensor | None = None,
-                        v_new: torch.Tensor | None = None) -> torch.Tensor:
+                        v_new: torch.Tensor | None = None, static_scratch: bool = False) -> torch.Tensor:
     """Planned paged decode attention (same result as decode_attn).  With k_new / v_new ([B, Hkv*D] rows of this
     step, inner stride 1) the KV slot write happens in the same launch (m355_decode_store_attn_planned): the
-    result and the pools are those of kv_store(...) followed by the attention."""
+    result and the pools are those of kv_store(...) followed by the attention.
+    static_scratch=True (needs k_new / v_new and a caller-owned `out`): m355_decode_store_attn_planned_static, which
+    keeps its partials in the library's own device array - nothing is allocated, by the library or by this wrapper."""
     lib = _lib.load()
     for n, t in (("q", q), ("k_pool", k_pool), ("v_pool", v_pool)):
         require_cuda(t, n)
@@ -244,14 +249,23 @@ def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Ten
         out = torch.empty((B, Hq * D), dtype=q.dtype, device=q.device)
     if scale is None:
         scale = float(D) ** -0.5
-    if workspace is None:                      # (a caller's workspace is size-checked by the library itself)
+    if workspace is None and not static_scratch:   # (a caller's workspace is size-checked by the library itself)
         workspace = torch.empty(decode_planned_workspace_bytes(B, Hq, Hkv, D, plan.capacity), dtype=torch.uint8,
                                 device=q.device)
+    if static_scratch and k_new is None:
+        raise _lib.MI355AttnError("decode_attn_planned: static_scratch is the fused-store form (pass k_new / v_new)")
     if k_new is not None:
         require_cuda(k_new, "k_new"), require_cuda(v_new, "v_new")
         k2, v2 = k_new.view(B, Hkv * D), v_new.view(B, Hkv * D)
         if k2.dtype != k_pool.dtype or v2.dtype != v_pool.dtype or k2.stride(1) != 1 or v2.stride(1) != 1:
             raise _lib.MI355AttnError("decode_attn_planned: k_new / v_new must have the pool dtype and inner stride 1")
+        if static_scratch:
+            check(lib.m355_decode_store_attn_planned_static(q2.data_ptr(), q2.stride(0), k2.data_ptr(), k2.stride(0),
+                                                            v2.data_ptr(), v2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(),
+                                                            plan.buf.data_ptr(), out.data_ptr(), out.stride(0), B, Hq, Hkv, D,
+                                                            scale, plan.capacity, dtype_code(q.dtype), current_stream()),
+                  "m355_decode_store_attn_planned_static")
+            return out
         check(lib.m355_decode_store_attn_planned(q2.data_ptr(), q2.stride(0), k2.data_ptr(), k2.stride(0), v2.data_ptr(),
                                                  v2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), plan.buf.data_ptr(),
                                                  out.data_ptr(), out.stride(0), B, Hq, Hkv, D, scale, plan.capacity,
