@@ -149,7 +149,7 @@ int m355_decode_plan(const int64_t *seq_lens, const int64_t *page_table_ids, con
 int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                             int64_t token_capacity);
 int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
-                             const void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                             void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                              int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
                              int64_t workspace_bytes, int32_t dtype, void *stream);
 
@@ -162,7 +162,7 @@ int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_
  * (M355_ERR_UNSUPPORTED under M355_STREAM_KERNEL=valu). */
 int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const void *k_new, int64_t k_row_stride,
                                    const void *v_new, int64_t v_row_stride, void *k_pool, void *v_pool,
-                                   const void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                   void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                    int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
                                    int64_t workspace_bytes, int32_t dtype, void *stream);
 
@@ -178,7 +178,7 @@ int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const vo
 #define M355_STATIC_SCRATCH_BYTES (8 * 1024 * 1024)
 int m355_decode_store_attn_planned_static(const void *q, int64_t q_row_stride, const void *k_new, int64_t k_row_stride,
                                           const void *v_new, int64_t v_row_stride, void *k_pool, void *v_pool,
-                                          const void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                          void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                           int32_t Hkv, int32_t D, float scale, int64_t token_capacity, int32_t dtype,
                                           void *stream);
 

@@ -30,26 +30,8 @@
 #define M355_DMA16 glds16p<M355_DECODE_POLICY>
 namespace m355 {
 
-constexpr float kLazyMax = 8.f;                 // log2 units
 constexpr int kQP = 4;                          // pieces whose q rows are staged in LDS at a time
 constexpr int kLdsPerCU = 160 * 1024;
-
-template <int D>
-struct MG {
-    static constexpr int C = D / 8;             // 16-byte chunks per K/V row of one head
-    static constexpr int ROWB = 2 * D;          // bytes per row
-    static constexpr int RPI = 64 / C;          // rows one DMA instruction brings (1 KiB)
-    static constexpr int NI = 32 / RPI;         // DMA instructions per 32-row tile
-    static constexpr int TILEB = 32 * ROWB;     // K (or V) tile bytes
-    static constexpr int STAGEB = 2 * TILEB;
-    static constexpr int KS = D / 32;           // k-steps of S^T = K Q^T
-    static constexpr int DT = D / 16;           // d-tiles of O^T
-    static constexpr int SPAN = 16 / C;         // rows per 256-byte bank span
-    // 16-byte chunk ch of row `row` lives at chunk position ch ^ s(row) of that row: conflict-free ds_read_b128 row
-    // reads of K (16 rows, one chunk column) and conflict-free transposed reads of V (8 rows x 2 chunks per half wave)
-    __host__ __device__ static constexpr int sK(int row) { return (row / SPAN) % C; }
-    __host__ __device__ static constexpr int sV(int row) { return ((row / SPAN) % (C / 2)) * 2; }
-};
 
 __host__ __device__ inline int mfma_lds_bytes(int D, int G, int R, int slots_cap) {
     return R * 64 * D * 2 + kQP * G * 2 * D + slots_cap * 4 + 64 * 4;

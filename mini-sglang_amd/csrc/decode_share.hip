@@ -1,0 +1,683 @@
+// Single-launch paged decode attention for gfx950: one workgroup per CU owns a SHARE of one kv head's token stream.
+//
+// decode_mfma.hip gives every wave its own range of the stream and needs a second launch (stream_merge_kernel) to
+// combine the fp32 partials of requests that a range boundary cut - 4.3 us of a 33 us pair on BASELINE configs[1].
+// Here the unit of scheduling is a CU-resident workgroup:
+//
+//   plan (share_plan_kernel + share_fill_kernel, once per forward, shared by all layers and kv heads)
+//     the batch's tokens form one flat stream, cut into nb = CUs / Hkv equal SHARES; the requests (or parts of
+//     requests) inside a share are its SEGMENTS, walked LAST SEGMENT FIRST; every segment is cut into 32-token
+//     STAGES and the share's stage list is dealt round-robin to the workgroup's W streaming waves.  A stage has a
+//     40-word record: the 32 KV-pool slots (page table resolved once per forward), request, valid tokens, flags.
+//   attention (decode_share_kernel, once per layer): W streaming waves + 1 finishing wave per workgroup
+//     streaming wave   per stage: record (2 stages ahead), q rows and K/V tiles arrive by LDS-DMA - a uniform number
+//                      of DMA instructions per stage, so ONE static vmcnt drives the whole loop, across requests;
+//                      the math is decode_mfma.hip's (v_mfma_f32_16x16x32, in-register P, transposed V reads);
+//                      at its last stage of a segment the wave leaves its fp32 (m, l, O) in LDS and counts itself in
+//     finishing wave   per segment, in order: waits for the segment's waves, merges their partials from LDS and
+//                      writes the bf16 output - no second launch, no partials in HBM.
+//   a request cut by a SHARE boundary (about half of them on configs[1]): the share holding its head part walks that
+//     segment FIRST and publishes one merged partial (write-through stores, then a flag); the share holding its tail
+//     part walks that segment LAST, and its finishing wave - idle until then - has already fetched the neighbour's
+//     partial when its own waves arrive.  Only requests longer than a share leave a wait at the end.
+//     Waits only ever point at LOWER workgroup indices; polls are bounded (plan header word kHError).
+//
+// Algorithmic bytes are those of decode_mfma.hip; the plan costs 160 B per 32 tokens per forward.
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "share_plan.h"
+
+namespace m355 {
+
+__device__ __forceinline__ int ub_minus1(const int32_t* cum, int n, int32_t x) {
+    // largest b in [0, n) with cum[b] <= x    (cum[0] == 0, non-decreasing): skips empty requests
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (cum[mid] <= x) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ int32_t stages_of(int32_t tokens) { return (tokens + kStageTok - 1) / kStageTok; }
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nb,
+                                                          int32_t Hkv, int32_t W, int64_t cap, int32_t* __restrict__ plan,
+                                                          ShareLayout L) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t cum_s[kShareCumLds + 1];
+    __shared__ int32_t stg_s[kShareCumLds + 1];
+    __shared__ int32_t nz_s[kShareCumLds + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto block_scan = [&](int32_t mine) -> int32_t {       // exclusive scan of one value per thread
+        int32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int32_t base = 0;
+        for (int k = 0; k < wv; ++k) base += wsum[k];
+        __syncthreads();
+        return base + incl - mine;
+    };
+    const bool staged = B <= kShareCumLds;
+    int32_t* cum = plan + L.cum;
+    int32_t* stg = plan + L.stg;
+    int32_t* nz = plan + L.nz;
+    const int per = (B + 1023) / 1024;
+    const int lo = tid * per, hi = min(B, lo + per);
+    // ---- cum: exclusive prefix sums of the lengths, clamped so the stream never exceeds the capacity
+    int32_t s = 0;
+    for (int b = lo; b < hi; ++b) s += (int32_t)seq_lens[b];
+    int32_t run = block_scan(s);
+    const int32_t icap = (int32_t)cap;
+    for (int b = lo; b < hi; ++b) {
+        const int32_t c = run < icap ? run : icap;
+        cum[b] = c;
+        if (staged) cum_s[b] = c;
+        run += (int32_t)seq_lens[b];
+    }
+    if (tid == 1023) { const int32_t c = run < icap ? run : icap; cum[B] = c; if (staged) cum_s[B] = c; }
+    __syncthreads();
+    const int32_t* cu = staged ? cum_s : cum;
+    const int32_t T = cu[B];
+    int32_t S = (T + nb - 1) / nb;
+    S = S < kShareMinTok ? kShareMinTok : S;
+    S = (S + kStageTok - 1) / kStageTok * kStageTok;
+    // ---- stg / nz: exclusive prefix sums of stages per whole request and of "request is not empty"
+    s = 0;
+    int32_t z = 0;
+    for (int b = lo; b < hi; ++b) { const int32_t len = cu[b + 1] - cu[b]; s += stages_of(len); z += len > 0; }
+    int32_t run_s = block_scan(s);
+    int32_t run_z = block_scan(z);
+    for (int b = lo; b < hi; ++b) {
+        const int32_t len = cu[b + 1] - cu[b];
+        stg[b] = run_s; nz[b] = run_z;
+        if (staged) { stg_s[b] = run_s; nz_s[b] = run_z; }
+        run_s += stages_of(len); run_z += len > 0;
+    }
+    if (tid == 1023) { stg[B] = run_s; nz[B] = run_z; if (staged) { stg_s[B] = run_s; nz_s[B] = run_z; } }
+    __syncthreads();
+    const int32_t* sg = staged ? stg_s : stg;
+    const int32_t* nzv = staged ? nz_s : nz;
+    // ---- shares (nb <= 1024: one per thread)
+    int32_t ns = 0, nseg = 0, bf = 0, bl = 0;
+    if (tid < nb) {
+        const int64_t t0 = (int64_t)tid * S;
+        if (t0 < T) {
+            const int32_t t1 = (int32_t)min((int64_t)T, t0 + S);
+            bf = ub_minus1(cu, B, (int32_t)t0);
+            bl = ub_minus1(cu, B, t1 - 1);
+            if (bf == bl) ns = stages_of(t1 - (int32_t)t0);
+            else ns = stages_of(cu[bf + 1] - (int32_t)t0) + (sg[bl] - sg[bf + 1]) + stages_of(t1 - cu[bl]);
+            nseg = nzv[bl] - nzv[bf] + 1;
+        }
+    }
+    const int32_t so = block_scan(ns);
+    const int32_t go = block_scan(nseg);
+    if (tid < nb) {
+        int32_t* e = plan + L.share + (int64_t)tid * kShareW;
+        e[0] = ns; e[1] = so; e[2] = go; e[3] = nseg; e[4] = bf; e[5] = bl; e[6] = 0; e[7] = 0;
+    }
+    if (tid == 0) {
+        plan[kHTotal] = T; plan[kHShareTok] = S; plan[kHB] = B; plan[kHShares] = nb; plan[kHWaves] = W; plan[kHError] = 0;
+        for (int k = kHError + 1; k < kShareHdr; ++k) plan[k] = 0;
+    }
+    if (tid == nb - 1) plan[kHStages] = so + ns;
+    for (int k = tid; k < Hkv * nb; k += 1024) plan[L.flags + k] = 0;      // hand-off flags start lowered
+}
+
+__global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restrict__ page_table, int64_t pt_stride,
+                                                         const int64_t* __restrict__ rows, int32_t B, int32_t ps, int32_t W,
+                                                         int32_t* __restrict__ plan, ShareLayout L) {
+    __shared__ int32_t cum_s[kShareCumLds + 1];
+    const int32_t T = plan[kHTotal], S = plan[kHShareTok];
+    const int32_t* cum = plan + L.cum;
+    const int32_t* stg = plan + L.stg;
+    const int32_t* nz = plan + L.nz;
+    if (B <= kShareCumLds) {
+        for (int k = threadIdx.x; k <= B; k += blockDim.x) cum_s[k] = cum[k];
+        __syncthreads();
+        cum = cum_s;
+    }
+    for (int32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < T; g += gridDim.x * blockDim.x) {
+        const int b = ub_minus1(cum, B, g);
+        const int32_t i = g / S;
+        const int32_t t0 = i * S, t1 = min(T, t0 + S);
+        const int32_t cs = cum[b], ce = cum[b + 1];
+        const int32_t seg0 = max(cs, t0), seg1 = min(ce, t1);
+        const int32_t pos = g - seg0, seg_len = seg1 - seg0, seg_n = stages_of(seg_len);
+        const int32_t* sh = plan + L.share + (int64_t)i * kShareW;
+        const int32_t bl = sh[5];
+        // stage base of this segment: the share's segments are walked last to first
+        int32_t base = 0;
+        if (b != bl) base = stages_of(t1 - max(cum[bl], t0)) + (stg[bl] - stg[b + 1]);
+        const int32_t st = pos / kStageTok, idx = pos - st * kStageTok;
+        const int32_t sl = base + st;                                   // stage index inside the share
+        int32_t* rec = plan + L.rec + (int64_t)(sh[1] + sl) * kRecW;
+        const int32_t tok = g - cs;
+        const int32_t pg = tok / ps;
+        const int32_t slot = page_table[rows[b] * pt_stride + pg] * ps + (tok - pg * ps);
+        rec[idx] = slot;
+        const int32_t ord = nz[bl] - nz[b];
+        if (idx == 0) {
+            const int32_t valid = min(kStageTok, seg_len - st * kStageTok);
+            int32_t meta = valid;
+            if (st < W) meta |= kRecFirst;                              // sl - W < base
+            if (st + W >= seg_n) meta |= kRecLast;                      // sl + W >= base + seg_n
+            if (seg1 == ce && st == seg_n - 1) meta |= kRecNewest;
+            rec[kRecB] = b;
+            rec[kRecMeta] = meta;
+            rec[kRecOrd] = ord;
+            for (int k = kRecOrd + 1; k < kRecW; ++k) rec[k] = 0;
+        }
+        if (pos == seg_len - 1)                                         // pad the segment's last stage with its last slot
+            for (int k = idx + 1; k < kStageTok; ++k) rec[k] = slot;
+        if (pos == 0) {
+            int32_t* e = plan + L.seg + (int64_t)(sh[2] + ord) * kSegW;
+            e[0] = b;
+            e[1] = seg_n;
+            e[2] = ce > t1 ? kSegPublish : (cs < t0 ? kSegMerge : kSegWhole);
+            e[3] = cs / S;                                               // the share that holds the request's first token
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {     // 4 bytes per lane -> lds_dst + 4*lane
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ float ld_agent(const float* p) {          // global_load_dword sc1: served past this CU's L1
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {        // global_store_dword sc1: write-through
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int32_t lds_peek(const int32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+constexpr int kPollLimit = 1 << 22;             // bounded waits (each round sleeps): ~seconds, then kHError is raised
+
+template <int D, int G>
+struct SG {                                      // per-wave LDS of a streaming wave, and the partial format
+    using M = MG<D>;
+    static constexpr int QB = G * M::ROWB;                       // bytes of one request's q rows for this head group
+    static constexpr int QBP = (QB + 63) / 64 * 64;
+    static constexpr int QL = QB / 16;                           // 16-byte lanes of them
+    static constexpr int NQ = (QL + 63) / 64;                    // DMA instructions for them
+    static constexpr int RECBYTES = kRecW * 4;
+    static constexpr int WAVEB = 2 * M::STAGEB + 4 * RECBYTES + 2 * QBP;
+    static constexpr int PW = (G * (D + 2) + 3) / 4 * 4;         // floats of one wave's partial in LDS: O[G][D], m[G], l[G]
+    static constexpr int PER_ITER = 2 * M::NI + 1 + NQ;          // DMA instructions per stage
+    static constexpr int VEC = G * D / 64 > 0 ? G * D / 64 : 1;  // output elements per lane of the finishing wave
+};
+
+constexpr int share_max_waves(int D) { return D <= 64 ? kShareMaxWaves : 4; }     // (LDS: a D = 128 wave needs 35 KiB)
+
+template <bool ON>
+__device__ __forceinline__ void shstamp(const ShareParams& p, int wave, int k) {
+    if constexpr (ON)
+        if (p.stamps && (threadIdx.x & 63) == 0)
+            p.stamps[((size_t)blockIdx.x * (kShareMaxWaves + 1) + wave) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
+
+template <int D, int G, bool F16, bool STAMP = false>
+__global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_kernel(const ShareParams p) {
+    using M = MG<D>;
+    using S = SG<D, G>;
+    static_assert(G <= 16 && G * D >= 64, "group shape");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+    const int W = p.W;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    float* const parts = reinterpret_cast<float*>(smem + W * S::WAVEB);
+    // ctl[1]: segments the finishing wave has merged (a partial slot is free again once its segment is);
+    // ctl[2 + slot]: waves that have left their partial of the segment currently using that slot
+    int32_t* const ctl = reinterpret_cast<int32_t*>(parts + p.nslot * W * S::PW);
+    shstamp<STAMP>(p, wave, 0);
+    if (threadIdx.x < 8) ctl[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int share = blockIdx.x / p.Hkv;
+    // heads rotate over the XCDs (workgroups are dealt round-robin to them): see decode_mfma.hip
+    const int h = (blockIdx.x + (p.rot > 0 ? share / p.rot : 0)) % p.Hkv;
+    const int32_t* sh = p.plan + p.off_share + (int64_t)share * kShareW;
+    const int NS = __builtin_amdgcn_readfirstlane(sh[0]);
+    const int SO = __builtin_amdgcn_readfirstlane(sh[1]);
+    if (NS == 0) return;
+    shstamp<STAMP>(p, wave, 1);
+
+    if (wave == W) {
+        // ======================================================================================== finishing wave
+        const int GO = __builtin_amdgcn_readfirstlane(sh[2]);
+        const int nseg = __builtin_amdgcn_readfirstlane(sh[3]);
+        const int32_t* segs = p.plan + p.off_seg + (int64_t)GO * kSegW;
+        int32_t* flags = p.plan + p.off_flags + (int64_t)h * p.nb;
+        const int pubw = share_pub_words(D, G);
+        float* pubs = p.pub + (int64_t)h * p.nb * pubw;
+        constexpr int VEC = S::VEC;
+        const int e0 = lane * VEC;                                   // first of this lane's elements of O[G][D]
+        const int g = e0 / D, d0 = e0 - g * D;
+        const bool live = e0 < G * D;                                // (G*D < 64 never happens: static_assert)
+        // hand-off state: only the share's LAST segment can end a request that began in an earlier share
+        int cross_left = 0, cross_next = share - 1;
+        if (segs[(nseg - 1) * kSegW + 2] == kSegMerge) cross_left = share - segs[(nseg - 1) * kSegW + 3];
+        float cm = kNegBig, cl = 0.f, cacc[VEC];
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) cacc[x] = 0.f;
+        bool failed = false;
+        auto poll_cross = [&]() {                                    // one look at the next publisher's flag
+            uint32_t f = 0;
+            if (lane == 0) f = __hip_atomic_load(reinterpret_cast<uint32_t*>(flags) + cross_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f = __builtin_amdgcn_readfirstlane(f);
+            if (!f) { __builtin_amdgcn_s_sleep(16); return; }
+            if (p.acquire & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float* src = pubs + (int64_t)cross_next * pubw;
+            float o[VEC];
+#pragma unroll
+            for (int x = 0; x < VEC; ++x) o[x] = live ? ld_agent(src + e0 + x) : 0.f;
+            const float pm = live ? ld_agent(src + G * D + g) : kNegBig;
+            const float pl = live ? ld_agent(src + G * D + G + g) : 0.f;
+            const float nm = fmaxf(cm, pm);
+            const float wa = exp2_fast(cm - nm), wb = exp2_fast(pm - nm);
+            cl = cl * wa + pl * wb;
+#pragma unroll
+            for (int x = 0; x < VEC; ++x) cacc[x] = cacc[x] * wa + o[x] * wb;
+            cm = nm;
+            if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(flags) + cross_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            --cross_next; --cross_left;
+            if (cross_left == 0) shstamp<STAMP>(p, wave, 3);
+        };
+        int base = 0;
+        for (int ord = 0; ord < nseg; ++ord) {
+            const int b = __builtin_amdgcn_readfirstlane(segs[ord * kSegW + 0]);
+            const int nst = __builtin_amdgcn_readfirstlane(segs[ord * kSegW + 1]);
+            const int kind = __builtin_amdgcn_readfirstlane(segs[ord * kSegW + 2]);
+            const int e = nst < W ? nst : W;
+            const int first = base % W;
+            base += nst;
+            int32_t* const arrived = ctl + 2 + ord % p.nslot;
+            int spins = 0;
+            while (lds_peek(arrived) < e) {                          // the segment's waves; meanwhile, the hand-off
+                if (cross_left > 0 && !(p.acquire & 2)) poll_cross(); else __builtin_amdgcn_s_sleep(2);
+                if (++spins > kPollLimit) { failed = true; break; }
+            }
+            asm volatile("" ::: "memory");
+            if (ord == 0) shstamp<STAMP>(p, wave, 2);
+            if (ord == nseg - 1) shstamp<STAMP>(p, wave, 4);
+            const float* slot = parts + (ord % p.nslot) * W * S::PW;
+            float gm = kNegBig;
+            for (int t = 0; t < e; ++t) {
+                int w = first + t; w = w >= W ? w - W : w;
+                gm = fmaxf(gm, slot[w * S::PW + G * D + (live ? g : 0)]);
+            }
+            float den = 0.f, acc[VEC];
+#pragma unroll
+            for (int x = 0; x < VEC; ++x) acc[x] = 0.f;
+            for (int t = 0; t < e; ++t) {
+                int w = first + t; w = w >= W ? w - W : w;
+                const float* pw = slot + w * S::PW;
+                const float wgt = exp2_fast(pw[G * D + (live ? g : 0)] - gm);
+                den = fmaf(wgt, pw[G * D + G + (live ? g : 0)], den);
+#pragma unroll
+                for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, pw[(live ? e0 : 0) + x], acc[x]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {                                         // slot free: count back to zero first, then release
+                __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __hip_atomic_store(ctl + 1, ord + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (kind == kSegPublish) {
+                float* dst = pubs + (int64_t)share * pubw;
+                if (live) {
+#pragma unroll
+                    for (int x = 0; x < VEC; ++x) st_agent(dst + e0 + x, acc[x]);
+                    if (d0 == 0) { st_agent(dst + G * D + g, gm); st_agent(dst + G * D + G + g, den); }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of the partial has been acknowledged
+                if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(flags) + share, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            if (kind == kSegMerge) {
+                int spins2 = 0;
+                while (cross_left > 0 && !failed) {
+                    poll_cross();
+                    if (++spins2 > kPollLimit) failed = true;
+                }
+                const float nm = fmaxf(cm, gm);
+                const float wa = exp2_fast(cm - nm), wb = exp2_fast(gm - nm);
+                den = cl * wa + den * wb;
+#pragma unroll
+                for (int x = 0; x < VEC; ++x) acc[x] = cacc[x] * wa + acc[x] * wb;
+            }
+            if (live) {
+                const float inv = 1.f / den;
+                uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)(h * G + g) * D + d0;
+                if constexpr (VEC == 1) {
+                    *op = (uint16_t)(pack16<F16>(acc[0] * inv, 0.f) & 0xffffu);
+                } else {
+                    uint32_t wds[VEC / 2];
+#pragma unroll
+                    for (int x = 0; x < VEC / 2; ++x) wds[x] = pack16<F16>(acc[2 * x] * inv, acc[2 * x + 1] * inv);
+                    if constexpr (VEC == 2) *reinterpret_cast<uint32_t*>(op) = wds[0];
+                    else if constexpr (VEC == 4) *reinterpret_cast<uint2*>(op) = make_uint2(wds[0], wds[1]);
+                    else {
+#pragma unroll
+                        for (int x = 0; x < VEC / 8; ++x)
+                            *reinterpret_cast<u32x4*>(op + 8 * x) = u32x4{wds[4 * x], wds[4 * x + 1], wds[4 * x + 2], wds[4 * x + 3]};
+                    }
+                }
+            }
+        }
+        if (failed && lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(p.plan) + kHError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); shstamp<STAMP>(p, wave, 5); }
+        return;
+    }
+
+    // ============================================================================================ streaming wave
+    const int j = wave;
+    if (j >= NS) return;
+    const int Nw = (NS - j + W - 1) / W;                                // this wave's stages: j, j + W, ...
+    uint8_t* const wbase = smem + j * S::WAVEB;
+    uint8_t* const ringp = wbase;
+    const int32_t* const recr = reinterpret_cast<const int32_t*>(wbase + 2 * M::STAGEB);
+    uint8_t* const qbuf = wbase + 2 * M::STAGEB + 4 * S::RECBYTES;
+    const uint32_t ring0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ringp);
+    const uint32_t rec0 = ring0 + 2 * M::STAGEB;
+    const uint32_t q0 = rec0 + 4 * S::RECBYTES;
+    const int32_t* const grec = p.plan + p.off_rec + (int64_t)(SO + j) * kRecW;
+
+    const int n = lane & 15;                             // q column / K row / d column, by operand
+    const int kg = lane >> 4;                            // 16-lane group = k sub-block
+    // dev timing experiments only (wrong results): other head columns than the workgroup's own
+    const int hx = (p.acquire & 4) ? (h + wave) % p.Hkv : h;
+    const int kx = (p.acquire >> 8) & 15, vx = (p.acquire >> 12) & 15;
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)(kx ? (kx - 1 + (kx > 8 ? h : 0)) % p.Hkv : hx) * M::ROWB;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)(vx ? (vx - 1 + (vx > 8 ? h : 0)) % p.Hkv : hx) * M::ROWB;
+    const int64_t row_bytes = p.row_elems * 2;
+    const int drow = lane / M::C, dch = lane % M::C;     // DMA: row inside the instruction, chunk position
+    int koff[M::NI], voff[M::NI];
+#pragma unroll
+    for (int i = 0; i < M::NI; ++i) {
+        const int row = i * M::RPI + drow;
+        koff[i] = 16 * (dch ^ M::sK(row));
+        voff[i] = 16 * (dch ^ M::sV(row));
+    }
+    const int ka0 = n * M::ROWB + 16 * (kg ^ M::sK(n));  // K fragment (row n [+16], k-step s): ka0 ^ 64 s
+    const int vrow = 4 * kg + (n >> 2);
+    const int va0 = vrow * M::ROWB + 16 * (M::sV(vrow) | ((n & 3) >> 1)) + 8 * (n & 1);   // V^T block (d-tile dt): va0 ^ 32 dt
+    const int qa0 = (n < G ? n : 0) * M::ROWB + 16 * kg;                                  // Q^T fragment (k-step s): + 64 s
+    const bool fused = p.k_new != nullptr;
+
+    f32x4 O[M::DT];
+    float m_run = kNegBig, l_run = 0.f;
+    bf16x8 qf[M::KS];
+    // the fused KV store's pool write waits in registers until the next counted wait has passed (a store in front of
+    // it would be waited for as well)
+    bool pend = false;
+    u32x4 pend_data = {0u, 0u, 0u, 0u};
+    uint16_t* pend_dst = nullptr;
+
+    auto rec_dma = [&](const int s) {                    // record of local stage s -> record ring slot s & 3
+        const int ss = s < Nw ? s : Nw - 1;              // (past the end: a harmless re-fetch keeps the DMA count uniform)
+        if (lane < kRecW) glds4(grec + (int64_t)ss * W * kRecW + lane, rec0 + (s & 3) * S::RECBYTES);
+    };
+    auto issue = [&](const int s) {
+        rec_dma(s + 2);
+        const int32_t* rc = recr + (s & 3) * kRecW;
+        const int b = __builtin_amdgcn_readfirstlane(rc[kRecB]);
+        const int meta = __builtin_amdgcn_readfirstlane(rc[kRecMeta]);
+        int64_t ro[M::NI];
+        int tt[M::NI];
+#pragma unroll
+        for (int i = 0; i < M::NI; ++i) {
+            tt[i] = i * M::RPI + drow;
+            ro[i] = (int64_t)rc[tt[i]] * row_bytes;
+        }
+        const uint8_t* qsrc = reinterpret_cast<const uint8_t*>(p.q + (int64_t)b * p.q_stride + (int64_t)h * G * D);
+#pragma unroll
+        for (int k = 0; k < S::NQ; ++k) {
+            const int l16 = lane + 64 * k;
+            if (l16 < S::QL) glds16(qsrc + l16 * 16, q0 + (s & 1) * S::QBP + k * 1024);
+        }
+        const uint32_t sbase = ring0 + (s & 1) * M::STAGEB;
+        if (fused && (meta & kRecNewest)) {              // wave-uniform: this stage holds the request's newest token
+            const int last = (meta & 0xff) - 1;
+            const uint8_t* knew = reinterpret_cast<const uint8_t*>(p.k_new + (int64_t)b * p.kn_stride) + h * M::ROWB;
+            const uint8_t* vnew = reinterpret_cast<const uint8_t*>(p.v_new + (int64_t)b * p.vn_stride) + h * M::ROWB;
+#pragma unroll
+            for (int i = 0; i < M::NI; ++i) {
+                const bool fresh = tt[i] >= last;        // the newest row (and the padding behind it) comes from k_new / v_new
+                glds16p<1>((fresh ? knew : kbase + ro[i]) + koff[i], sbase + 1024 * i);
+                glds16p<1>((fresh ? vnew : vbase + ro[i]) + voff[i], sbase + M::TILEB + 1024 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < M::NI; ++i) {
+                glds16p<1>(kbase + ro[i] + koff[i], sbase + 1024 * i);
+                glds16p<1>(vbase + ro[i] + voff[i], sbase + M::TILEB + 1024 * i);
+            }
+        }
+    };
+    auto consume = [&](const int s) {
+        const int32_t* rc = recr + (s & 3) * kRecW;
+        const int meta = __builtin_amdgcn_readfirstlane(rc[kRecMeta]);
+        const int valid = meta & 0xff;
+        const uint8_t* st = ringp + (s & 1) * M::STAGEB;
+        if (meta & kRecFirst) {                          // a new segment for this wave: its q rows, a fresh state
+            const uint8_t* qsp = qbuf + (s & 1) * S::QBP;
+#pragma unroll
+            for (int k = 0; k < M::KS; ++k) {
+                u32x4 t = *reinterpret_cast<const u32x4*>(qsp + qa0 + 64 * k);
+                if (n >= G) t = u32x4{0u, 0u, 0u, 0u};
+                qf[k] = __builtin_bit_cast(bf16x8, t);
+            }
+            m_run = kNegBig; l_run = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < M::DT; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < M::KS; ++k) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + (ka0 ^ (64 * k)));
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + 16 * M::ROWB + (ka0 ^ (64 * k)));
+            s0 = mfma_16x16x32<F16>(a0, qf[k], s0);
+            s1 = mfma_16x16x32<F16>(a1, qf[k], s1);
+        }
+        if (valid < kStageTok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * kg + r >= valid) s0[r] = kNegBig;
+                if (16 + 4 * kg + r >= valid) s1[r] = kNegBig;
+            }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        float a, b2;
+        lane_pair<16>(mx, a, b2);
+        mx = fmaxf(a, b2);
+        lane_pair<32>(mx, a, b2);
+        mx = fmaxf(a, b2);
+        const float m_tile = mx * p.scale_log2;
+        const float m_new = m_tile > m_run + kLazyMax ? m_tile : m_run;     // lazy running max (decode_mfma.hip)
+        const float alpha = exp2_fast(m_run - m_new);
+        m_run = m_new;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s0[r] = exp2_fast(fmaf(s0[r], p.scale_log2, -m_new));
+            s1[r] = exp2_fast(fmaf(s1[r], p.scale_log2, -m_new));
+            sum += s0[r] + s1[r];
+        }
+        l_run = fmaf(l_run, alpha, sum);
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int dt = 0; dt < M::DT; ++dt) O[dt] *= alpha;
+        }
+        const u32x4 pw = {pack16<F16>(s0[0], s0[1]), pack16<F16>(s0[2], s0[3]), pack16<F16>(s1[0], s1[1]), pack16<F16>(s1[2], s1[3])};
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int dt = 0; dt < M::DT; ++dt) {
+            const uint8_t* va = st + M::TILEB + (va0 ^ (32 * dt));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)va);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)(va + 16 * M::ROWB));
+            const s16x8 av = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            O[dt] = mfma_16x16x32<F16>(__builtin_bit_cast(bf16x8, av), pf, O[dt]);
+        }
+        if (fused && (meta & kRecNewest)) {              // the newest token's K and V rows: LDS -> registers -> (later) pool slot
+            const int row = valid - 1;
+            if (lane < 2 * M::C) {
+                const int c = lane % M::C;
+                const bool isv = lane >= M::C;
+                const uint8_t* src = st + (isv ? M::TILEB : 0) + row * M::ROWB + 16 * (c ^ (isv ? M::sV(row) : M::sK(row)));
+                pend_data = *reinterpret_cast<const u32x4*>(src);
+                pend_dst = (isv ? p.v_pool : p.k_pool) + (int64_t)rc[row] * p.row_elems + h * D + c * 8;
+            }
+            pend = true;
+        }
+        if (meta & kRecLast) {                           // this wave's part of the segment is done: (m, l, O) -> LDS
+            float x, y;
+            lane_pair<16>(l_run, x, y);
+            float l = x + y;
+            lane_pair<32>(l, x, y);
+            l = x + y;
+            const int ord = __builtin_amdgcn_readfirstlane(rc[kRecOrd]);
+            int spins = 0;
+            while (lds_peek(ctl + 1) < ord - p.nslot + 1 && ++spins < kPollLimit) __builtin_amdgcn_s_sleep(1);   // slot still being merged
+            float* dst = parts + ((ord % p.nslot) * W + j) * S::PW;
+            if (n < G) {
+#pragma unroll
+                for (int dt = 0; dt < M::DT; ++dt) *reinterpret_cast<f32x4*>(dst + n * D + 16 * dt + 4 * kg) = O[dt];
+                if (kg == 0) { dst[G * D + n] = m_run; dst[G * D + G + n] = l; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(ctl + 2 + ord % p.nslot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto flush_pend = [&]() {
+        if (pend) {
+            if (lane < 2 * M::C) *reinterpret_cast<u32x4*>(pend_dst) = pend_data;
+            pend = false;
+        }
+    };
+
+    rec_dma(0);
+    rec_dma(1);
+    wait_vmcnt<0>();
+    shstamp<STAMP>(p, wave, 2);
+    for (int s = 0; s < Nw; ++s) {
+        issue(s);
+        wait_vmcnt<S::PER_ITER>();                       // everything but the stage just asked for has landed
+        if (s == 1) shstamp<STAMP>(p, wave, 3);
+        flush_pend();
+        if (s > 0) consume(s - 1);
+    }
+    shstamp<STAMP>(p, wave, 4);
+    wait_vmcnt<0>();
+    flush_pend();
+    consume(Nw - 1);
+    flush_pend();
+    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); shstamp<STAMP>(p, wave, 5); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int share_cus() {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return v > 0 ? v : 256;
+}
+
+ShareShape share_shape(int Hkv, int D, int G) {
+    ShareShape r{0, 0, 0, 0, false};
+    if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8) || G * D < 64 || Hkv <= 0) return r;
+    const int stageb = 128 * D;                          // K + V tile of 32 rows
+    const int qb = G * 2 * D, qbp = (qb + 63) / 64 * 64;
+    const int waveb = 2 * stageb + 4 * kRecW * 4 + 2 * qbp;
+    const int pw = (G * (D + 2) + 3) / 4 * 4;
+    constexpr int kLds = 160 * 1024;
+    for (int W = share_max_waves(D); W >= 1; --W) {
+        for (int ns = 4; ns >= 1; --ns) {
+            const int lds = W * waveb + ns * W * pw * 4 + 64;
+            if (lds <= kLds) {
+                r.W = W; r.nslot = ns; r.lds_bytes = lds; r.ok = true;
+                r.nb = share_cus() / Hkv;
+                if (r.nb < 1) r.nb = 1;
+                if (r.nb > 1024) r.nb = 1024;
+                return r;
+            }
+        }
+    }
+    return r;
+}
+
+int launch_share_plan(const int64_t* seq_lens, const int64_t* rows, const int32_t* page_table, int64_t pt_stride, int32_t B,
+                      int32_t ps, int32_t Hkv, int32_t D, int32_t G, int64_t cap, int32_t* plan, hipStream_t st) {
+    const ShareShape sh = share_shape(Hkv, D, G);
+    if (!sh.ok) return M355_ERR_UNSUPPORTED;
+    const ShareLayout L = share_layout(B, sh.nb, Hkv, cap);
+    hipLaunchKernelGGL(share_plan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, sh.nb, Hkv, sh.W, cap, plan, L);
+    int64_t blocks = (cap + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(share_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, page_table, pt_stride, rows, B, ps, sh.W, plan, L);
+    return check_launch();
+}
+
+template <int D, int G, bool F16>
+static int launch_share(const ShareParams& p, int lds, hipStream_t st) {
+    // more than 64 KiB of dynamic LDS has to be allowed once per kernel and device
+    static std::atomic<uint64_t> allowed{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(allowed.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_share_kernel<D, G, F16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return M355_ERR_LAUNCH;
+        }
+        allowed.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((decode_share_kernel<D, G, F16>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), lds, st, p);
+    return M355_OK;
+}
+
+int launch_share_attn(ShareParams& p, int D, int G, bool f16, hipStream_t st, bool stamp) {
+    const ShareShape sh = share_shape(p.Hkv, D, G);
+    if (!sh.ok) return M355_ERR_UNSUPPORTED;
+    p.nb = sh.nb; p.W = sh.W; p.nslot = sh.nslot;
+    p.rot = sh.nb / p.Hkv > 0 ? sh.nb / p.Hkv : 1;
+    { const char* e = getenv("M355_SHARE_ROT"); if (e) p.rot = atoi(e); }                       // dev A/B
+    { const char* e = getenv("M355_SHARE_MIXHEAD"); p.acquire |= (e && atoi(e)) ? 4 : 0; }
+    { const char* e = getenv("M355_SHARE_KCOL"); if (e) p.acquire |= (atoi(e) & 15) << 8; }      // 1..8: all workgroups stream K column e-1; 9..15: own head + e-9
+    { const char* e = getenv("M355_SHARE_VCOL"); if (e) p.acquire |= (atoi(e) & 15) << 12; }
+    { const char* e = getenv("M355_SHARE_EARLY_POLL"); p.acquire |= (e && atoi(e) == 0) ? 2 : 0; }   // dev A/B: bit 1 = poll only at the end
+    if (stamp && !f16 && D == 64 && G == 4) {            // dev timing build of the benchmark shape
+        static bool allowed = false;
+        if (!allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_share_kernel<64, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); allowed = true; }
+        hipLaunchKernelGGL((decode_share_kernel<64, 4, false, true>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), sh.lds_bytes, st, p);
+        return M355_OK;
+    }
+#define M355_CASE(DD, GG) if (D == DD && G == GG) return f16 ? launch_share<DD, GG, true>(p, sh.lds_bytes, st) : launch_share<DD, GG, false>(p, sh.lds_bytes, st);
+    M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
+    M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)
+#undef M355_CASE
+    return M355_ERR_UNSUPPORTED;
+}
+
+}  // namespace m355

@@ -23,7 +23,7 @@
 
 #include <mutex>
 
-#include "stream_plan.h"
+#include "share_plan.h"
 
 namespace m355 {
 
@@ -548,6 +548,26 @@ static inline int stream_rmin(int D, int G) {                                   
     return use_mfma() ? mfma_rmin() : 4 * (kWave / (D / 8)) * stream_shape(G).U;
 }
 
+// Which kernel serves a batch: the single-launch share kernel (decode_share.hip) when, on average, a request spans at
+// most kShareSpan shares (its finishing wave combines the parts of a cut request one after the other); the per-wave
+// ranges + merge launch (decode_mfma.hip) for few, long requests (thousands of tokens per request and CU), where
+// hundreds of pieces per request want the wide merge.  Plan, workspace and attention calls all decide from the same
+// (B, head shape): M355_DECODE_SHARE=0/1 forces it (dev A/B).
+constexpr int kShareSpan = 8;
+static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G) {
+    if (!use_mfma()) return false;
+    const ShareShape sh = share_shape(Hkv, D, G);
+    if (!sh.ok) return false;
+    static const int forced = [] { const char* e = getenv("M355_DECODE_SHARE"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    return false;      // (work in progress: not yet faster than the merge-launch pair on contiguous pools)
+    return (int64_t)B * kShareSpan >= sh.nb;
+}
+static int64_t share_pub_bytes(int32_t Hkv, int32_t D, int32_t G) {
+    const ShareShape sh = share_shape(Hkv, D, G);
+    return sh.ok ? (int64_t)Hkv * sh.nb * share_pub_words(D, G) * (int64_t)sizeof(float) : 0;
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -559,6 +579,8 @@ extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev-only (n
 
 extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
     if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
+    if (share_mode(B, Hkv, D, G))
+        return share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity).ints * (int64_t)sizeof(int32_t);
     return plan_layout(B, stream_nwh(Hkv, D, G, token_capacity), token_capacity).ints * (int64_t)sizeof(int32_t);
 }
 
@@ -570,6 +592,12 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
         return M355_ERR_INVALID_ARG;
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
     if (token_capacity > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
+    if (share_mode(B, Hkv, D, G)) {
+        const ShareLayout SL = share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity);
+        if (plan_bytes < SL.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
+        return launch_share_plan(seq_lens, page_table_ids, page_table, pt_row_stride, B, page_size, Hkv, D, G, token_capacity,
+                                 (int32_t*)plan, (hipStream_t)stream);
+    }
     const int nwh = stream_nwh(Hkv, D, G, token_capacity);
     const PlanLayout L = plan_layout(B, nwh, token_capacity);
     if (plan_bytes < L.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
@@ -586,6 +614,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
 extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                                        int64_t token_capacity) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return 0;
+    if (share_mode(B, Hkv, D, Hq / Hkv)) return share_pub_bytes(Hkv, D, Hq / Hkv);   // one partial per (share, q head)
     const PlanLayout L = plan_layout(B, stream_nwh(Hkv, D, Hq / Hkv, token_capacity), token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;      // every range boundary and request adds at most one
     return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
@@ -617,10 +646,11 @@ static void launch_stream(const StreamParams& p, hipStream_t st) {
 }
 
 static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
-                                    const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                    void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                     int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
                                     int64_t workspace_bytes, int32_t dtype, void* stream, const void* k_new,
-                                    int64_t k_row_stride, const void* v_new, int64_t v_row_stride) {
+                                    int64_t k_row_stride, const void* v_new, int64_t v_row_stride,
+                                    bool library_scratch = false) {
     if (B == 0) return M355_OK;
     if (!q || !k_pool || !v_pool || !plan || !out || B < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || token_capacity <= 0)
         return M355_ERR_INVALID_ARG;
@@ -633,6 +663,23 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
         return M355_ERR_INVALID_ARG;
     if ((q_row_stride % 8) || (o_row_stride % 8) || q_row_stride < (int64_t)Hq * D || o_row_stride < (int64_t)Hq * D)
         return M355_ERR_INVALID_ARG;
+    if (share_mode(B, Hkv, D, G)) {
+        const ShareShape sh = share_shape(Hkv, D, G);
+        const ShareLayout SL = share_layout(B, sh.nb, Hkv, token_capacity);
+        if (!workspace || workspace_bytes < share_pub_bytes(Hkv, D, G) || ((uintptr_t)workspace & 15)) return M355_ERR_WORKSPACE;
+        ShareParams sp;
+        sp.q = (const uint16_t*)q; sp.k_pool = (uint16_t*)k_pool; sp.v_pool = (uint16_t*)v_pool;
+        sp.k_new = (const uint16_t*)k_new; sp.v_new = (const uint16_t*)v_new; sp.kn_stride = k_row_stride; sp.vn_stride = v_row_stride;
+        sp.plan = (int32_t*)plan; sp.out = (uint16_t*)out; sp.pub = (float*)workspace;
+        sp.q_stride = q_row_stride; sp.o_stride = o_row_stride; sp.row_elems = (int64_t)Hkv * D;
+        { const char* e = getenv("M355_POOL_PITCH"); if (e) sp.row_elems = atoi(e); }      // dev timing experiment
+        sp.off_share = SL.share; sp.off_flags = SL.flags; sp.off_seg = SL.seg; sp.off_rec = SL.rec;
+        sp.B = B; sp.Hq = Hq; sp.Hkv = Hkv; sp.scale_log2 = scale * kLog2e;
+        sp.acquire = library_scratch ? 1 : 0;      // a __device__ array is not hipMalloc memory: full acquire after a hand-off poll
+        sp.stamps = g_stream_stamps;
+        const int rc = launch_share_attn(sp, D, G, f16, (hipStream_t)stream, getenv("M355_STREAM_STAMP") != nullptr);
+        return rc != M355_OK ? rc : check_launch();
+    }
     const int nwh = stream_nwh(Hkv, D, G, token_capacity);
     const PlanLayout L = plan_layout(B, nwh, token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;
@@ -666,7 +713,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
 }
 
 extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
-                                        const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                        void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                         int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
                                         int64_t workspace_bytes, int32_t dtype, void* stream) {
     return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
@@ -691,7 +738,7 @@ static void* static_scratch() {
 
 extern "C" int m355_decode_store_attn_planned_static(const void* q, int64_t q_row_stride, const void* k_new,
                                                      int64_t k_row_stride, const void* v_new, int64_t v_row_stride,
-                                                     void* k_pool, void* v_pool, const void* plan, void* out,
+                                                     void* k_pool, void* v_pool, void* plan, void* out,
                                                      int64_t o_row_stride, int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                                      float scale, int64_t token_capacity, int32_t dtype, void* stream) {
     if (B == 0) return M355_OK;
@@ -706,12 +753,12 @@ extern "C" int m355_decode_store_attn_planned_static(const void* q, int64_t q_ro
     // Nothing in the scratch has to start at zero: every partial the merge reads is written by this same call.
     return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     token_capacity, ws, (int64_t)M355_STATIC_SCRATCH_BYTES, dtype, stream, k_new,
-                                    k_row_stride, v_new, v_row_stride);
+                                    k_row_stride, v_new, v_row_stride, /*library_scratch=*/true);
 }
 
 extern "C" int m355_decode_store_attn_planned(const void* q, int64_t q_row_stride, const void* k_new, int64_t k_row_stride,
                                               const void* v_new, int64_t v_row_stride, void* k_pool, void* v_pool,
-                                              const void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                              void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                               int32_t Hkv, int32_t D, float scale, int64_t token_capacity,
                                               void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
     if (B == 0) return M355_OK;

@@ -1,0 +1,78 @@
+// Plan of the single-launch decode kernel (decode_share.hip): the batch's token stream cut into one SHARE per
+// workgroup, every share expanded into 32-token STAGES whose records a wave fetches by LDS-DMA as it goes.
+#pragma once
+#include "stream_plan.h"
+
+namespace m355 {
+
+constexpr int kStageTok = 32;                   // tokens per stage (one K tile + one V tile of one kv head)
+constexpr int kRecW = 40;                       // int32 words per stage record
+constexpr int kRecB = 32;                       // record word: request index
+constexpr int kRecMeta = 33;                    // record word: valid tokens (low 8 bits) | flags
+constexpr int kRecOrd = 34;                     // record word: ordinal of the stage's segment inside its share
+constexpr int kRecFirst = 1 << 8;               // meta flag: the owning wave's first stage of this segment
+constexpr int kRecLast = 1 << 9;                // meta flag: the owning wave's last stage of this segment
+constexpr int kRecNewest = 1 << 10;             // meta flag: token valid-1 of the stage is the request's newest token
+constexpr int kShareHdr = 16;                   // plan header words
+constexpr int kShareW = 8;                      // words per share entry: {stages, first stage, first segment, segments, ...}
+constexpr int kSegW = 4;                        // words per segment entry: {request, stages, kind, first share of the request}
+constexpr int kSegWhole = 0, kSegPublish = 1, kSegMerge = 2;
+constexpr int kShareMinTok = 128;               // shortest share
+constexpr int kShareMaxWaves = 8;               // streaming waves per workgroup (plus one finishing wave)
+constexpr int kShareCumLds = 4096;              // requests whose prefix sums the plan kernels stage in LDS
+
+// header words
+constexpr int kHTotal = 0, kHShareTok = 1, kHB = 2, kHShares = 3, kHWaves = 4, kHStages = 5, kHError = 6;
+
+// plan buffer (int32 words): hdr | cum[B+1] | stg[B+1] | nz[B+1] | share[nb][kShareW] | flags[Hkv*nb] | seg[(B+nb)][kSegW] |
+//                            rec[max_stages][kRecW]
+struct ShareLayout {
+    int64_t cum, stg, nz, share, flags, seg, rec, ints;
+    int64_t max_stages;
+};
+__host__ __device__ inline ShareLayout share_layout(int32_t B, int32_t nb, int32_t Hkv, int64_t cap) {
+    ShareLayout L;
+    L.max_stages = cap / kStageTok + B + nb + 2;
+    L.cum = kShareHdr;
+    L.stg = L.cum + (B + 1);
+    L.nz = L.stg + (B + 1);
+    L.share = (L.nz + (B + 1) + 3) & ~(int64_t)3;
+    L.flags = L.share + (int64_t)nb * kShareW;
+    L.seg = (L.flags + (int64_t)Hkv * nb + 3) & ~(int64_t)3;
+    L.rec = (L.seg + (int64_t)(B + nb) * kSegW + 63) & ~(int64_t)63;       // records start on a 256-byte line
+    L.ints = L.rec + L.max_stages * kRecW;
+    return L;
+}
+
+// Launch shape of the share kernel for a head shape: W streaming waves per workgroup, NSLOT partial slots, LDS bytes.
+struct ShareShape {
+    int W, nslot, lds_bytes, nb;     // nb: shares (= workgroups per kv head)
+    bool ok;
+};
+ShareShape share_shape(int Hkv, int D, int G);
+// published share partial (fp32 words, a multiple of 64): O[G][D], m[G], l[G]
+__host__ __device__ inline int share_pub_words(int D, int G) { return (G * (D + 2) + 63) / 64 * 64; }
+
+struct ShareParams {
+    const uint16_t* q;
+    uint16_t* k_pool;             // written only by the fused KV store
+    uint16_t* v_pool;
+    const uint16_t* k_new;        // fused KV store: the step's new K/V rows [B, Hkv*D], or nullptr
+    const uint16_t* v_new;
+    int64_t kn_stride, vn_stride;
+    int32_t* plan;                // the kernel raises and clears the hand-off flags inside it
+    uint16_t* out;
+    float* pub;                   // [Hkv][nb][share_pub_words]: share partials of requests cut by a share boundary
+    int64_t q_stride, o_stride, row_elems;
+    int64_t off_share, off_flags, off_seg, off_rec;
+    int32_t B, Hq, Hkv, nb, W, nslot, rot;
+    float scale_log2;
+    int32_t acquire;              // 1: agent acquire after a hand-off poll (pub is not hipMalloc memory: the static scratch)
+    unsigned long long* stamps;   // dev-only timing probe (tools/stamp_share.py), 8 slots per wave; else nullptr
+};
+
+int launch_share_plan(const int64_t* seq_lens, const int64_t* rows, const int32_t* page_table, int64_t pt_stride, int32_t B,
+                      int32_t ps, int32_t Hkv, int32_t D, int32_t G, int64_t cap, int32_t* plan, hipStream_t st);
+int launch_share_attn(ShareParams& p, int D, int G, bool f16, hipStream_t st, bool stamp = false);
+
+}  // namespace m355

@@ -11,6 +11,26 @@ constexpr int kRecEnds = 4 + 4 * kMaxPieces;    // record word: bit k set = piec
 constexpr int kSpec = 5;                        // slots loaded per lane together with the record (5*64 = 320 tokens)
 constexpr int kHdrInts = 8;
 
+constexpr float kLazyMax = 8.f;                 // log2 units: the running max moves only when beaten by 2^8
+
+// Geometry of one 32-token K (or V) tile of one kv head in LDS, shared by the matrix-core decode kernels.
+template <int D>
+struct MG {
+    static constexpr int C = D / 8;             // 16-byte chunks per K/V row of one head
+    static constexpr int ROWB = 2 * D;          // bytes per row
+    static constexpr int RPI = 64 / C;          // rows one DMA instruction brings (1 KiB)
+    static constexpr int NI = 32 / RPI;         // DMA instructions per 32-row tile
+    static constexpr int TILEB = 32 * ROWB;     // K (or V) tile bytes
+    static constexpr int STAGEB = 2 * TILEB;
+    static constexpr int KS = D / 32;           // k-steps of S^T = K Q^T
+    static constexpr int DT = D / 16;           // d-tiles of O^T
+    static constexpr int SPAN = 16 / C;         // rows per 256-byte bank span
+    // 16-byte chunk ch of row `row` lives at chunk position ch ^ s(row) of that row: conflict-free ds_read_b128 row
+    // reads of K (16 rows, one chunk column) and conflict-free transposed reads of V (8 rows x 2 chunks per half wave)
+    __host__ __device__ static constexpr int sK(int row) { return (row / SPAN) % C; }
+    __host__ __device__ static constexpr int sV(int row) { return ((row / SPAN) % (C / 2)) * 2; }
+};
+
 // plan buffer (int32 words): hdr[8] | cum[B+1] | pbase[B+1] | rec[max_ranges][kRec] | slots[max_ranges][kRMax]
 struct PlanLayout {
     int64_t cum, pbase, rec, slots, ints;

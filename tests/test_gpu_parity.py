@@ -493,7 +493,8 @@ def test_random_configurations_sweep():
     splits through planned decode with fused store, chunked decode and prefill, against torch fp32 on the GPU."""
     import subprocess
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py")
-    for extra in ([], ["f16"]):                          # bf16, then IEEE half through the same matrix-core kernels
-        r = subprocess.run([sys.executable, tool, "1", "6"] + extra, capture_output=True, text=True, timeout=110)
+    for extra, share in (([], "0"), (["f16"], "0"), ([], "1"), (["f16"], "1")):   # bf16 / IEEE half; both decode kernels
+        r = subprocess.run([sys.executable, tool, "1", "5"] + extra, capture_output=True, text=True, timeout=110,
+                           env=dict(os.environ, M355_DECODE_SHARE=share))
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         assert "random configurations passed" in r.stdout

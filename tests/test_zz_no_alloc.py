@@ -70,13 +70,15 @@ def test_static_scratch_entry_equals_workspace_entry():
     from mi355_attn import _lib, ops
     lib = _lib.load()
     rng = np.random.default_rng(0)
-    # 1. cfg2-sized: B = 64 ragged, 1B head shape - most requests are cut into several pieces (partials in the scratch)
+    # 1. cfg2-sized: B = 64 ragged, 1B head shape: the single-launch kernel, whose scratch holds the partials of the
+    #    requests a share boundary cuts (handed over between workgroups)
     lens = [int(x) for x in rng.integers(64, 2049, size=64)]
     need1 = _run_both(ops, lib, 64, 32, 8, 64, 16, lens, seed=1)
-    # 2. right after it, a SMALLER batch with another head shape: reuses the front of the same scratch array
+    # 2. right after it, a SMALLER batch with another head shape (few requests per CU: per-wave ranges + merge
+    #    launch, whose fp32 partials reuse the front of the same scratch array)
     lens2 = [int(x) for x in rng.integers(1, 700, size=5)]
     need2 = _run_both(ops, lib, 5, 8, 1, 128, 16, lens2, seed=2)
-    assert need2 < need1 <= ops.STATIC_SCRATCH_BYTES
+    assert sum(lens2) < sum(lens) and max(need1, need2) <= ops.STATIC_SCRATCH_BYTES
     # 3. the wrapper form, page_size 1
     table, kp, vp, qkv = _case(3, 16, 4, 128, 1, [300, 17, 1], 3)
     dqkv = qkv.to(DEV)
@@ -92,7 +94,7 @@ def test_static_scratch_entry_equals_workspace_entry():
 def test_static_scratch_entry_refuses_what_does_not_fit():
     from mi355_attn import _lib, ops
     lib = _lib.load()
-    B, Hq, Hkv, D, cap = 4096, 32, 8, 128, 4096 * 64
+    B, Hq, Hkv, D, cap = 16, 8, 1, 128, 1 << 21        # few, very long requests: thousands of fp32 partials
     assert lib.m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap) > ops.STATIC_SCRATCH_BYTES
     x = torch.zeros(4096, dtype=torch.bfloat16, device=DEV)       # any valid, aligned device pointer: nothing is launched
     rc = lib.m355_decode_store_attn_planned_static(x.data_ptr(), Hq * D, x.data_ptr(), Hkv * D, x.data_ptr(), Hkv * D,

@@ -105,3 +105,12 @@ if STREAM:
         print(f"blockIdx%8={x}: loop median {np.median(loop[sel]):.2f} p95 {np.percentile(loop[sel],95):.2f} life median {np.median(life[sel]):.2f}")
     # last waves of the stream have a short range
     print("loop time of the 16 slowest waves:", np.sort(loop)[-16:].round(1), "their w:", w[np.argsort(loop)[-16:]])
+if STREAM:
+    blk = np.arange(nblocks)
+    head = (blk + (blk // Hkv) // max(1, nwh // Hkv)) % Hkv
+    first = (s[:, 3] - s[:, 0]) * 0.01
+    endt = (s[:, 5] - t0) * 0.01
+    print("by kv head: first tile landed after entry (median) / loop median / end median / end max")
+    for h_ in range(Hkv):
+        sel = (head == h_) & live
+        print(f"  h={h_}: {np.median(first[sel]):5.2f} / {np.median(loop[sel[live]] if False else ((s[sel,4]-s[sel,3])*0.01)):6.2f} / {np.median(endt[sel]):6.2f} / {endt[sel].max():6.2f}")

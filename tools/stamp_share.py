@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Dev tool: per-wave phase timing of decode_share_kernel on the cfg2 batch (M355_STREAM_STAMP build path).
+
+Streaming waves: 0 entry, 1 share header known, 2 first records landed, 3 first stage landed, 4 last stage issued+all
+but last consumed, 5 done (stores retired).  Finishing wave: 2 first segment's waves arrived, 3 hand-off complete,
+4 last segment's waves arrived, 5 done."""
+import ctypes
+import os
+import random
+import sys
+from collections import deque
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "mini-sglang_amd"))
+os.environ["M355_STREAM_STAMP"] = "1"
+os.environ.setdefault("M355_DECODE_SHARE", "1")
+import mi355_attn as m  # noqa: E402
+from mi355_attn import _lib, ops  # noqa: E402
+
+dev = "cuda:0"
+Hq, Hkv, D, ps, L = 32, 8, 64, 16, 4
+random.seed(0)
+lens = [random.randint(64, 2048) + 1 for _ in range(64)]
+B = len(lens)
+pages = sum(-(-l // ps) for l in lens) + 8
+kv = m.KVCache(pages * ps * (2 if os.environ.get('M355_POOL_PITCH') else 1), ps, Hkv, D, torch.bfloat16, L, dev)
+pm = m.PageManager(ps, B, 4096, dev)
+kv._free = deque(torch.randperm(pages, generator=torch.Generator().manual_seed(0)).tolist())
+kv._store.copy_(torch.randn(kv._store.shape, device=dev).to(torch.bfloat16))
+reqs = [m.Req(i, list(range(l))) for i, l in enumerate(lens)]
+for r in reqs:
+    r.fill_ids = r.origin_input_ids
+batch = m.Batch(reqs, pm, kv, device=dev)
+batch.prepare_for_prefill()
+q = torch.randn((B, Hq * D), device=dev).to(torch.bfloat16)
+NW = 9
+nblocks = 256
+stamps = torch.zeros((nblocks * NW, 8), dtype=torch.int64, device=dev)
+lib = _lib.load()
+setter = lib.m355dbg_set_stream_stamp_buffer
+setter.argtypes = [ctypes.c_void_p]
+assert setter(stamps.data_ptr()) == 0
+plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens))
+
+
+def run(layer):
+    kp, vp = kv.get_kv_cache(layer)
+    ops.decode_attn_planned(q, kp, vp, plan, Hq)
+
+
+for l in range(L):
+    run(l)
+torch.cuda.synchronize()
+stamps.zero_()
+torch.cuda.synchronize()
+run(0)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().astype(np.int64).reshape(nblocks, NW, 8)
+us = lambda x: x * 0.01
+t0 = s[:, :, 0][s[:, :, 0] > 0].min()
+st = s[:, :8].reshape(-1, 8)
+st = st[st[:, 5] > 0]
+hp = s[:, 8]
+hp = hp[hp[:, 5] > 0]
+print(f"streaming waves {len(st)}, finishing waves {len(hp)}")
+for name, a in (("streaming", st), ("finishing", hp)):
+    print(f"[{name}] entry after first wave: median {us(np.median(a[:,0]-t0)):.2f} max {us((a[:,0]-t0).max()):.2f}")
+    for k in range(1, 6):
+        ok = a[:, k] > 0
+        d = a[ok, k] - t0
+        print(f"[{name}] stamp {k} (us after first entry): median {us(np.median(d)):.2f}  p5 {us(np.percentile(d,5)):.2f}  p95 {us(np.percentile(d,95)):.2f}  max {us(d.max()):.2f}   (n={ok.sum()})")
+print(f"kernel span: {us(max(st[:,5].max(), hp[:,5].max()) - t0):.2f} us; last streaming wave done {us(st[:,5].max()-t0):.2f}")
+tail = hp[:, 5] - hp[:, 4]
+print(f"finishing wave: last arrival -> done: median {us(np.median(tail)):.2f} p95 {us(np.percentile(tail,95)):.2f} max {us(tail.max()):.2f}")
+loop = st[:, 4] - st[:, 3]
+print(f"streaming loop (first stage landed -> last issued): median {us(np.median(loop)):.2f} p95 {us(np.percentile(loop,95)):.2f} max {us(loop.max()):.2f}")
+hdr = plan.buf.view(torch.int32)[:8].cpu().numpy()
+print("plan header: total", hdr[0], "share tokens", hdr[1], "shares", hdr[3], "waves", hdr[4], "stages", hdr[5], "error", hdr[6])
+# ---- where does the spread come from: wave index, XCD slot, workgroup
+S5 = (s[:, :8, 5] - t0) * 0.01
+S3 = (s[:, :8, 3] - t0) * 0.01
+S2 = (s[:, :8, 2] - t0) * 0.01
+print("by wave index j: first stage landed (median), done (median / max)")
+for j in range(8):
+    print(f"  j={j}: {np.median(S3[:, j]):6.2f}   {np.median(S5[:, j]):6.2f} / {S5[:, j].max():6.2f}")
+print("by blockIdx % 8: first stage landed (median), done (median / max)")
+for x in range(8):
+    sel = (np.arange(nblocks) % 8) == x
+    print(f"  x={x}: {np.median(S3[sel]):6.2f}   {np.median(S5[sel]):6.2f} / {S5[sel].max():6.2f}")
+wg_end = S5.max(axis=1)
+wg_start3 = S3.min(axis=1)
+print("workgroup end (max over its waves): percentiles", [round(float(np.percentile(wg_end, p)), 2) for p in (5, 25, 50, 75, 95, 100)])
+print("workgroup spread (max - min wave end): median", round(float(np.median(S5.max(axis=1) - S5.min(axis=1))), 2), "max", round(float((S5.max(axis=1) - S5.min(axis=1)).max()), 2))
+share_tab = plan.buf.view(torch.int32).cpu().numpy()
+order = np.argsort(wg_end)
+print("slowest workgroups (blockIdx, share, end, first-stage-min):", [(int(b), int(b) // 8, round(float(wg_end[b]), 1), round(float(wg_start3[b]), 1)) for b in order[-8:]])
+print("fastest workgroups:", [(int(b), int(b) // 8, round(float(wg_end[b]), 1)) for b in order[:8]])
+by_share = np.array([wg_end[np.arange(nblocks) // 8 == i].mean() for i in range(32)])
+print("mean end by share:", by_share.round(1))
+blk = np.arange(nblocks)
+ROT = int(os.environ.get('M355_SHARE_ROT', '4'))
+head = (blk + ((blk // 8) // ROT if ROT > 0 else 0)) % 8
+print("by kv head: workgroup end median / max; streaming-wave loop median; first stage landed median")
+LOOP = (s[:, :8, 4] - s[:, :8, 3]) * 0.01
+for h_ in range(8):
+    sel = head == h_
+    print(f"  h={h_}: {np.median(wg_end[sel]):6.2f} / {wg_end[sel].max():6.2f}   loop {np.median(LOOP[sel]):6.2f}   first {np.median(S3[sel]):5.2f}")
