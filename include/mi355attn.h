@@ -10,6 +10,11 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless its comment says "host";
  *   - strides are in ELEMENTS of the pointed-to type;
+ *   - pool_row_stride: elements between consecutive token rows of a K or V pool ([S, Hkv, D] with a row pitch; 0 means
+ *     contiguous, Hkv*D - the reference's own tensors, memory/kvcache.py:24-35).  A multiple of 8, >= Hkv*D.  A pool
+ *     whose pitch is an ODD number of 128-byte lines (mi355_attn.KVCache pads 128 bytes per row) spreads every kv
+ *     head's column over all address-interleave patterns; on MI355X a CU that streams ONE 128-byte column of a
+ *     contiguous pool runs up to 30 % slower on some columns;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream);
  *     no entry point synchronises, allocates or frees;
  *   - return value: M355_OK (0) or a negative M355_ERR_* code; nothing throws or exits;
@@ -52,7 +57,7 @@ const char *m355_strerror(int code);
  * views of the packed qkv projection, models/llama.py:133-134), inner stride 1, 16-byte aligned
  * rows.  Pure byte copy, bit-exact; negative slots wrap like torch indexing, out-of-range slots
  * are skipped.  dtype selects the element size only (bf16/f16: 2 bytes, f32: 4 bytes). */
-int m355_kv_store(void *k_pool, void *v_pool, const void *k_src, const void *v_src,
+int m355_kv_store(void *k_pool, void *v_pool, int64_t pool_row_stride, const void *k_src, const void *v_src,
                   int64_t k_row_stride, int64_t v_row_stride, const int64_t *loc, int32_t T,
                   int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void *stream);
 
@@ -127,7 +132,7 @@ int m355_decode_prepare_ring(int32_t *page_table, int64_t pt_row_stride, int32_t
 int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t D, int32_t max_seq_len_hint,
                                     int32_t chunk_tokens);
 int m355_decode_attn(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
-                     const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
+                     int64_t pool_row_stride, const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
                      const int64_t *seq_lens, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                      int32_t Hkv, int32_t D, int32_t page_size, float scale, int32_t max_seq_len_hint,
                      int32_t chunk_tokens, void *workspace, int64_t workspace_bytes, int32_t dtype,
@@ -149,7 +154,7 @@ int m355_decode_plan(const int64_t *seq_lens, const int64_t *page_table_ids, con
 int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                             int64_t token_capacity);
 int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
-                             void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                             int64_t pool_row_stride, void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                              int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
                              int64_t workspace_bytes, int32_t dtype, void *stream);
 
@@ -162,7 +167,7 @@ int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_
  * (M355_ERR_UNSUPPORTED under M355_STREAM_KERNEL=valu). */
 int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const void *k_new, int64_t k_row_stride,
                                    const void *v_new, int64_t v_row_stride, void *k_pool, void *v_pool,
-                                   void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                   int64_t pool_row_stride, void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                    int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
                                    int64_t workspace_bytes, int32_t dtype, void *stream);
 
@@ -178,7 +183,7 @@ int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const vo
 #define M355_STATIC_SCRATCH_BYTES (8 * 1024 * 1024)
 int m355_decode_store_attn_planned_static(const void *q, int64_t q_row_stride, const void *k_new, int64_t k_row_stride,
                                           const void *v_new, int64_t v_row_stride, void *k_pool, void *v_pool,
-                                          void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                          int64_t pool_row_stride, void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                           int32_t Hkv, int32_t D, float scale, int64_t token_capacity, int32_t dtype,
                                           void *stream);
 
@@ -193,7 +198,7 @@ int m355_decode_store_attn_planned_static(const void *q, int64_t q_row_stride, c
  * launch is cut into KV splits - few query rows over long histories - whose partials a second kernel merges). */
 int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D, int32_t max_seq_len_hint);
 int m355_prefill_attn(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
-                      const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
+                      int64_t pool_row_stride, const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
                       const int64_t *seq_lens, const int64_t *prefix_lens, const int32_t *cu_q,
                       void *out, int64_t o_row_stride, int32_t B, int32_t T, int32_t max_extend_len,
                       int32_t max_seq_len_hint, int32_t Hq, int32_t Hkv, int32_t D, int32_t page_size,
@@ -212,8 +217,8 @@ int m355_prefill_attn(const void *q, int64_t q_row_stride, const void *k_pool, c
  * kernel the reference actually calls is unpinned (wheel not available). */
 int m355_rope_kv_store(void *q, int64_t q_row_stride, void *k, int64_t k_row_stride, const void *v,
                        int64_t v_row_stride, const int64_t *positions, const float *cos_sin_cache,
-                       int64_t max_position, void *k_pool, void *v_pool, const int64_t *loc, int32_t T,
-                       int32_t Hq, int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void *stream);
+                       int64_t max_position, void *k_pool, void *v_pool, int64_t pool_row_stride,
+                       const int64_t *loc, int32_t T, int32_t Hq, int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void *stream);
 
 #ifdef __cplusplus
 }

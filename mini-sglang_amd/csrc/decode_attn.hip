@@ -445,7 +445,8 @@ static void launch_decode(const DecodeParams& p, hipStream_t st) {
 
 // Shared by m355_decode_attn (cu_q == null: one query per request) and by the row-parallel extend path of
 // m355_prefill_attn (cu_q/prefix_lens given: NQ packed query rows, each treated as its own decode query).
-int paged_rows_attn(const void* q, int64_t q_stride, const void* k_pool, const void* v_pool, const int32_t* page_table,
+int paged_rows_attn(const void* q, int64_t q_stride, const void* k_pool, const void* v_pool, int64_t pool_row_stride,
+                    const int32_t* page_table,
                     int64_t pt_stride, const int64_t* row_ids, const int64_t* kv_lens, const int32_t* cu_q,
                     const int64_t* prefix_lens, int32_t B, void* out, int64_t o_stride, int64_t NQ, int32_t Hq,
                     int32_t Hkv, int32_t D, int32_t ps, float scale, int32_t max_len_hint, int32_t chunk,
@@ -470,7 +471,7 @@ int paged_rows_attn(const void* q, int64_t q_stride, const void* k_pool, const v
     p.q = (const uint16_t*)q; p.k_pool = (const uint16_t*)k_pool; p.v_pool = (const uint16_t*)v_pool;
     p.page_table = page_table; p.row_ids = row_ids; p.kv_lens = kv_lens; p.out = (uint16_t*)out;
     p.cu_q = cu_q; p.prefix_lens = prefix_lens; p.B = B;
-    p.q_stride = q_stride; p.o_stride = o_stride; p.pt_stride = pt_stride; p.row_elems = (int64_t)Hkv * D;
+    p.q_stride = q_stride; p.o_stride = o_stride; p.pt_stride = pt_stride; p.row_elems = pool_row_stride ? pool_row_stride : (int64_t)Hkv * D;
     p.NQ = (int32_t)NQ; p.Hq = Hq; p.Hkv = Hkv; p.ps = ps; p.ps_shift = ilog2_exact(ps);
     p.chunk = chunk; p.max_splits = max_splits; p.scale_log2 = scale * kLog2e;
     p.ws_o = nullptr; p.ws_ml = nullptr;
@@ -510,12 +511,13 @@ extern "C" int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t D,
 }
 
 extern "C" int m355_decode_attn(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
-                                const int32_t* page_table, int64_t pt_row_stride, const int64_t* page_table_ids,
+                                int64_t pool_row_stride, const int32_t* page_table, int64_t pt_row_stride, const int64_t* page_table_ids,
                                 const int64_t* seq_lens, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                 int32_t Hkv, int32_t D, int32_t page_size, float scale, int32_t max_seq_len_hint,
                                 int32_t chunk_tokens, void* workspace, int64_t workspace_bytes, int32_t dtype,
                                 void* stream) {
-    return m355::paged_rows_attn(q, q_row_stride, k_pool, v_pool, page_table, pt_row_stride, page_table_ids, seq_lens,
+    if (pool_row_stride && (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8)) return M355_ERR_INVALID_ARG;
+    return m355::paged_rows_attn(q, q_row_stride, k_pool, v_pool, pool_row_stride, page_table, pt_row_stride, page_table_ids, seq_lens,
                                  nullptr, nullptr, B, out, o_row_stride, B, Hq, Hkv, D, page_size, scale,
                                  max_seq_len_hint, chunk_tokens, workspace, workspace_bytes, dtype, (hipStream_t)stream);
 }

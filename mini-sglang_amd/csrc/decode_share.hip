@@ -22,7 +22,7 @@
 //     partial when its own waves arrive.  Only requests longer than a share leave a wait at the end.
 //     Waits only ever point at LOWER workgroup indices; polls are bounded (plan header word kHError).
 //
-// Algorithmic bytes are those of decode_mfma.hip; the plan costs 160 B per 32 tokens per forward.
+// Algorithmic bytes are those of decode_mfma.hip; the plan costs 160 B per 32 tokens per forward.  No workspace.
 #include <stdlib.h>
 
 #include <atomic>
@@ -44,6 +44,11 @@ __device__ __forceinline__ int32_t stages_of(int32_t tokens) { return (tokens + 
 
 // ------------------------------------------------------------------------------------------------
 // plan
+//
+// Coordinates: request b has stages_of(len_b) stages; laid end to end they form the STAGE stream, stage v of which is
+// 32 consecutive tokens of one request counted from that request's start (its last stage may be partial).  Shares are
+// equal pieces of Q stages of that stream, so every workgroup streams the same number of K/V tiles, and a request is
+// only ever cut at a multiple of 32 of its own tokens (no cut adds a partial stage).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nb,
                                                           int32_t Hkv, int32_t W, int64_t cap, int32_t* __restrict__ plan,
@@ -87,11 +92,7 @@ __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restr
     if (tid == 1023) { const int32_t c = run < icap ? run : icap; cum[B] = c; if (staged) cum_s[B] = c; }
     __syncthreads();
     const int32_t* cu = staged ? cum_s : cum;
-    const int32_t T = cu[B];
-    int32_t S = (T + nb - 1) / nb;
-    S = S < kShareMinTok ? kShareMinTok : S;
-    S = (S + kStageTok - 1) / kStageTok * kStageTok;
-    // ---- stg / nz: exclusive prefix sums of stages per whole request and of "request is not empty"
+    // ---- stg / nz: exclusive prefix sums of stages per request and of "request is not empty"
     s = 0;
     int32_t z = 0;
     for (int b = lo; b < hi; ++b) { const int32_t len = cu[b + 1] - cu[b]; s += stages_of(len); z += len > 0; }
@@ -106,39 +107,34 @@ __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restr
     if (tid == 1023) { stg[B] = run_s; nz[B] = run_z; if (staged) { stg_s[B] = run_s; nz_s[B] = run_z; } }
     __syncthreads();
     const int32_t* sg = staged ? stg_s : stg;
-    const int32_t* nzv = staged ? nz_s : nz;
-    // ---- shares (nb <= 1024: one per thread)
-    int32_t ns = 0, nseg = 0, bf = 0, bl = 0;
-    if (tid < nb) {
-        const int64_t t0 = (int64_t)tid * S;
-        if (t0 < T) {
-            const int32_t t1 = (int32_t)min((int64_t)T, t0 + S);
-            bf = ub_minus1(cu, B, (int32_t)t0);
-            bl = ub_minus1(cu, B, t1 - 1);
-            if (bf == bl) ns = stages_of(t1 - (int32_t)t0);
-            else ns = stages_of(cu[bf + 1] - (int32_t)t0) + (sg[bl] - sg[bf + 1]) + stages_of(t1 - cu[bl]);
-            nseg = nzv[bl] - nzv[bf] + 1;
-        }
-    }
-    const int32_t so = block_scan(ns);
-    const int32_t go = block_scan(nseg);
+    const int32_t TS = sg[B];
+    int32_t Q = (TS + nb - 1) / nb;
+    Q = Q < kShareMinStages ? kShareMinStages : Q;
+    // ---- shares (nb <= 1024: one per thread): the first and the last request that have stages in it
     if (tid < nb) {
         int32_t* e = plan + L.share + (int64_t)tid * kShareW;
-        e[0] = ns; e[1] = so; e[2] = go; e[3] = nseg; e[4] = bf; e[5] = bl; e[6] = 0; e[7] = 0;
+        const int64_t s0 = (int64_t)tid * Q;
+        int32_t bf = 0, bl = -1;
+        if (s0 < TS) {
+            const int32_t s1 = (int32_t)min((int64_t)TS, s0 + Q);
+            bf = ub_minus1(sg, B, (int32_t)s0);
+            bl = ub_minus1(sg, B, s1 - 1);
+        }
+        e[0] = bf; e[1] = bl;
+        for (int k = 2; k < kShareW; ++k) e[k] = 0;
     }
     if (tid == 0) {
-        plan[kHTotal] = T; plan[kHShareTok] = S; plan[kHB] = B; plan[kHShares] = nb; plan[kHWaves] = W; plan[kHError] = 0;
+        plan[kHTotal] = cu[B]; plan[kHShareStages] = Q; plan[kHB] = B; plan[kHShares] = nb; plan[kHWaves] = W;
+        plan[kHStages] = TS; plan[kHError] = 0;
         for (int k = kHError + 1; k < kShareHdr; ++k) plan[k] = 0;
     }
-    if (tid == nb - 1) plan[kHStages] = so + ns;
-    for (int k = tid; k < Hkv * nb; k += 1024) plan[L.flags + k] = 0;      // hand-off flags start lowered
 }
 
 __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restrict__ page_table, int64_t pt_stride,
                                                          const int64_t* __restrict__ rows, int32_t B, int32_t ps, int32_t W,
                                                          int32_t* __restrict__ plan, ShareLayout L) {
     __shared__ int32_t cum_s[kShareCumLds + 1];
-    const int32_t T = plan[kHTotal], S = plan[kHShareTok];
+    const int32_t T = plan[kHTotal], Q = plan[kHShareStages], TS = plan[kHStages];
     const int32_t* cum = plan + L.cum;
     const int32_t* stg = plan + L.stg;
     const int32_t* nz = plan + L.nz;
@@ -147,46 +143,35 @@ __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restri
         __syncthreads();
         cum = cum_s;
     }
+    // hand-off granules start lowered (the attention kernel lowers what it consumed; this covers a fresh buffer)
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < L.gran_words; k += (int64_t)gridDim.x * blockDim.x) plan[L.gran + k] = 0;
     for (int32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < T; g += gridDim.x * blockDim.x) {
         const int b = ub_minus1(cum, B, g);
-        const int32_t i = g / S;
-        const int32_t t0 = i * S, t1 = min(T, t0 + S);
-        const int32_t cs = cum[b], ce = cum[b + 1];
-        const int32_t seg0 = max(cs, t0), seg1 = min(ce, t1);
-        const int32_t pos = g - seg0, seg_len = seg1 - seg0, seg_n = stages_of(seg_len);
-        const int32_t* sh = plan + L.share + (int64_t)i * kShareW;
-        const int32_t bl = sh[5];
-        // stage base of this segment: the share's segments are walked last to first
-        int32_t base = 0;
-        if (b != bl) base = stages_of(t1 - max(cum[bl], t0)) + (stg[bl] - stg[b + 1]);
-        const int32_t st = pos / kStageTok, idx = pos - st * kStageTok;
-        const int32_t sl = base + st;                                   // stage index inside the share
-        int32_t* rec = plan + L.rec + (int64_t)(sh[1] + sl) * kRecW;
-        const int32_t tok = g - cs;
+        const int32_t tok = g - cum[b], len = cum[b + 1] - cum[b];
+        const int32_t sb0 = stg[b], sb1 = stg[b + 1];
+        const int32_t v = sb0 + tok / kStageTok, idx = tok % kStageTok;      // stage of the stream, place inside it
+        const int32_t i = v / Q;
+        const int32_t s0 = i * Q, s1 = min(TS, s0 + Q);
+        const int32_t a = max(sb0, s0), e = min(sb1, s1);                     // the segment = this request's stages in the share
+        const int32_t st = v - a, seg_n = e - a;
+        const int32_t sl = (s1 - e) + st;                                     // the share's segments are walked last to first
+        int32_t* rec = plan + L.rec + (int64_t)(s0 + sl) * kRecW;
         const int32_t pg = tok / ps;
         const int32_t slot = page_table[rows[b] * pt_stride + pg] * ps + (tok - pg * ps);
         rec[idx] = slot;
-        const int32_t ord = nz[bl] - nz[b];
         if (idx == 0) {
-            const int32_t valid = min(kStageTok, seg_len - st * kStageTok);
-            int32_t meta = valid;
-            if (st < W) meta |= kRecFirst;                              // sl - W < base
-            if (st + W >= seg_n) meta |= kRecLast;                      // sl + W >= base + seg_n
-            if (seg1 == ce && st == seg_n - 1) meta |= kRecNewest;
+            const int32_t bl = plan[L.share + (int64_t)i * kShareW + 1];
+            int32_t meta = min(kStageTok, len - (tok / kStageTok) * kStageTok);
+            if (st < W) meta |= kRecFirst;                              // the owning wave's previous stage lies before the segment
+            if (st + W >= seg_n) meta |= kRecLast;                      // ... its next one behind it
+            if (v == sb1 - 1) meta |= kRecNewest;                       // the request's last stage holds its newest token
             rec[kRecB] = b;
             rec[kRecMeta] = meta;
-            rec[kRecOrd] = ord;
+            rec[kRecOrd] = nz[bl] - nz[b];
             for (int k = kRecOrd + 1; k < kRecW; ++k) rec[k] = 0;
         }
-        if (pos == seg_len - 1)                                         // pad the segment's last stage with its last slot
+        if (tok == len - 1)                                             // pad the request's last stage with its last slot
             for (int k = idx + 1; k < kStageTok; ++k) rec[k] = slot;
-        if (pos == 0) {
-            int32_t* e = plan + L.seg + (int64_t)(sh[2] + ord) * kSegW;
-            e[0] = b;
-            e[1] = seg_n;
-            e[2] = ce > t1 ? kSegPublish : (cs < t0 ? kSegMerge : kSegWhole);
-            e[3] = cs / S;                                               // the share that holds the request's first token
-        }
     }
 }
 
@@ -220,7 +205,6 @@ struct SG {                                      // per-wave LDS of a streaming 
     static constexpr int RECBYTES = kRecW * 4;
     static constexpr int WAVEB = 2 * M::STAGEB + 4 * RECBYTES + 2 * QBP;
     static constexpr int PW = (G * (D + 2) + 3) / 4 * 4;         // floats of one wave's partial in LDS: O[G][D], m[G], l[G]
-    static constexpr int PER_ITER = 2 * M::NI + 1 + NQ;          // DMA instructions per stage
     static constexpr int VEC = G * D / 64 > 0 ? G * D / 64 : 1;  // output elements per lane of the finishing wave
 };
 
@@ -247,81 +231,114 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
     // ctl[2 + slot]: waves that have left their partial of the segment currently using that slot
     int32_t* const ctl = reinterpret_cast<int32_t*>(parts + p.nslot * W * S::PW);
     shstamp<STAMP>(p, wave, 0);
-    if (threadIdx.x < 8) ctl[threadIdx.x] = 0;
-    __syncthreads();
-
+    if (threadIdx.x < 8) ctl[threadIdx.x] = 0;           // (the one workgroup barrier that publishes this comes below, behind each
+                                                         // wave's first loads)
     const int share = blockIdx.x / p.Hkv;
     // heads rotate over the XCDs (workgroups are dealt round-robin to them): see decode_mfma.hip
     const int h = (blockIdx.x + (p.rot > 0 ? share / p.rot : 0)) % p.Hkv;
-    const int32_t* sh = p.plan + p.off_share + (int64_t)share * kShareW;
-    const int NS = __builtin_amdgcn_readfirstlane(sh[0]);
-    const int SO = __builtin_amdgcn_readfirstlane(sh[1]);
-    if (NS == 0) return;
+    const int Q = __builtin_amdgcn_readfirstlane(p.plan[kHShareStages]);
+    const int TS = __builtin_amdgcn_readfirstlane(p.plan[kHStages]);
+    const int SO = share * Q;                                        // the share = stages [SO, SO + NS) of the stream
+    const int NS = TS - SO < Q ? TS - SO : Q;
+    if (NS <= 0) return;
     shstamp<STAMP>(p, wave, 1);
 
     if (wave == W) {
         // ======================================================================================== finishing wave
-        const int GO = __builtin_amdgcn_readfirstlane(sh[2]);
-        const int nseg = __builtin_amdgcn_readfirstlane(sh[3]);
-        const int32_t* segs = p.plan + p.off_seg + (int64_t)GO * kSegW;
-        int32_t* flags = p.plan + p.off_flags + (int64_t)h * p.nb;
-        const int pubw = share_pub_words(D, G);
-        float* pubs = p.pub + (int64_t)h * p.nb * pubw;
+        __syncthreads();
+        const int32_t* sh = p.plan + p.off_share + (int64_t)share * kShareW;
+        const int bf = __builtin_amdgcn_readfirstlane(sh[0]);
+        const int bl = __builtin_amdgcn_readfirstlane(sh[1]);
+        const int32_t* stg = p.plan + p.off_stg;
+        const int S1 = SO + NS;
         constexpr int VEC = S::VEC;
+        constexpr int NG = VEC + 2;                                  // granules per lane: its VEC elements of O, m and l of its q head
+        // hand-off area of (kv head h, share i): NG x 64 granules {fp32 value, tag}, granule k of lane L at (k*64 + L)
+        unsigned long long* const gran = reinterpret_cast<unsigned long long*>(p.plan + p.off_gran) + (int64_t)h * p.nb * (NG * 64);
         const int e0 = lane * VEC;                                   // first of this lane's elements of O[G][D]
         const int g = e0 / D, d0 = e0 - g * D;
-        const bool live = e0 < G * D;                                // (G*D < 64 never happens: static_assert)
         // hand-off state: only the share's LAST segment can end a request that began in an earlier share
         int cross_left = 0, cross_next = share - 1;
-        if (segs[(nseg - 1) * kSegW + 2] == kSegMerge) cross_left = share - segs[(nseg - 1) * kSegW + 3];
+        {
+            const int f0 = __builtin_amdgcn_readfirstlane(stg[bf]);
+            if (f0 < SO && __builtin_amdgcn_readfirstlane(stg[bf + 1]) <= S1) cross_left = share - f0 / Q;   // shares f0/Q .. share-1 publish
+        }
         float cm = kNegBig, cl = 0.f, cacc[VEC];
 #pragma unroll
         for (int x = 0; x < VEC; ++x) cacc[x] = 0.f;
         bool failed = false;
-        auto poll_cross = [&]() {                                    // one look at the next publisher's flag
-            uint32_t f = 0;
-            if (lane == 0) f = __hip_atomic_load(reinterpret_cast<uint32_t*>(flags) + cross_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f = __builtin_amdgcn_readfirstlane(f);
-            if (!f) { __builtin_amdgcn_s_sleep(16); return; }
-            if (p.acquire & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const float* src = pubs + (int64_t)cross_next * pubw;
-            float o[VEC];
+        // The hand-off runs BESIDE the segment loop and never makes it wait: a publisher's partial travels as 8-byte
+        // granules {value, tag}, each written by ONE write-through store, so there is no flag and no ordering to wait
+        // for; this wave loads the next publisher's granules in one call of cross_step and looks at them kCrossLag calls
+        // later, when they have long landed (a global access of a streaming CU takes ~4 us; a wave stalled on it would
+        // not see its own streaming waves arrive, and they would wait for their partial slot).  All tags raised: the
+        // partial is folded into (cm, cl, cacc) and its granules are lowered again for the next launch.
+        constexpr int kCrossLag = 20;
+        int cstate = 0, cage = 0;
+        unsigned long long cg[NG];
 #pragma unroll
-            for (int x = 0; x < VEC; ++x) o[x] = live ? ld_agent(src + e0 + x) : 0.f;
-            const float pm = live ? ld_agent(src + G * D + g) : kNegBig;
-            const float pl = live ? ld_agent(src + G * D + G + g) : 0.f;
+        for (int x = 0; x < NG; ++x) cg[x] = 0ull;
+        auto cross_step = [&](const bool hurry) {
+            unsigned long long* src = gran + (int64_t)cross_next * (NG * 64) + lane;
+            if (cstate == 0) {
+#pragma unroll
+                for (int x = 0; x < NG; ++x) cg[x] = __hip_atomic_load(src + x * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cstate = 1; cage = 0;
+                return;
+            }
+            if (!hurry && ++cage < kCrossLag) return;
+            bool mine = true;
+#pragma unroll
+            for (int x = 0; x < NG; ++x) mine = mine && (uint32_t)(cg[x] >> 32) == 1u;
+            cstate = 0;
+            if (!__all(mine)) return;                                // not (all) there yet: look again
+            shstamp<STAMP>(p, wave, 6);
+            const float pm = __builtin_bit_cast(float, (uint32_t)cg[VEC]), pl = __builtin_bit_cast(float, (uint32_t)cg[VEC + 1]);
             const float nm = fmaxf(cm, pm);
             const float wa = exp2_fast(cm - nm), wb = exp2_fast(pm - nm);
             cl = cl * wa + pl * wb;
 #pragma unroll
-            for (int x = 0; x < VEC; ++x) cacc[x] = cacc[x] * wa + o[x] * wb;
+            for (int x = 0; x < VEC; ++x) cacc[x] = cacc[x] * wa + __builtin_bit_cast(float, (uint32_t)cg[x]) * wb;
             cm = nm;
-            if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(flags) + cross_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int x = 0; x < NG; ++x) __hip_atomic_store(src + x * 64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             --cross_next; --cross_left;
             if (cross_left == 0) shstamp<STAMP>(p, wave, 3);
         };
-        int base = 0;
-        for (int ord = 0; ord < nseg; ++ord) {
-            const int b = __builtin_amdgcn_readfirstlane(segs[ord * kSegW + 0]);
-            const int nst = __builtin_amdgcn_readfirstlane(segs[ord * kSegW + 1]);
-            const int kind = __builtin_amdgcn_readfirstlane(segs[ord * kSegW + 2]);
+        // the segments, last request first; their stage ranges come from stg, 64 requests per load
+        int base = 0, ord = 0;
+        int wb = bl + 1;                                             // lanes hold requests wb-1, wb-2, ... of the current window
+        int32_t w0 = 0, w1 = 0;
+        for (int b = bl; b >= bf; --b) {
+            if (b < wb - 63 || b == bl) {
+                wb = b + 1;
+                const int bb = b - lane;
+                w0 = bb >= bf ? stg[bb] : 0;
+                w1 = bb >= bf ? stg[bb + 1] : 0;
+            }
+            const int sb0 = __shfl(w0, wb - 1 - b), sb1 = __shfl(w1, wb - 1 - b);
+            if (sb1 == sb0) continue;                                // empty request
+            const int lo_ = sb0 > SO ? sb0 : SO, hi_ = sb1 < S1 ? sb1 : S1;
+            const int nst = hi_ - lo_;
+            const int kind = sb1 > S1 ? kSegPublish : (sb0 < SO ? kSegMerge : kSegWhole);
             const int e = nst < W ? nst : W;
             const int first = base % W;
             base += nst;
             int32_t* const arrived = ctl + 2 + ord % p.nslot;
             int spins = 0;
             while (lds_peek(arrived) < e) {                          // the segment's waves; meanwhile, the hand-off
-                if (cross_left > 0 && !(p.acquire & 2)) poll_cross(); else __builtin_amdgcn_s_sleep(2);
+                if (cross_left > 0) cross_step(false);
+                __builtin_amdgcn_s_sleep(2);
                 if (++spins > kPollLimit) { failed = true; break; }
             }
             asm volatile("" ::: "memory");
             if (ord == 0) shstamp<STAMP>(p, wave, 2);
-            if (ord == nseg - 1) shstamp<STAMP>(p, wave, 4);
+            if (b == bf) shstamp<STAMP>(p, wave, 4);
             const float* slot = parts + (ord % p.nslot) * W * S::PW;
             float gm = kNegBig;
             for (int t = 0; t < e; ++t) {
                 int w = first + t; w = w >= W ? w - W : w;
-                gm = fmaxf(gm, slot[w * S::PW + G * D + (live ? g : 0)]);
+                gm = fmaxf(gm, slot[w * S::PW + G * D + g]);
             }
             float den = 0.f, acc[VEC];
 #pragma unroll
@@ -329,10 +346,10 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             for (int t = 0; t < e; ++t) {
                 int w = first + t; w = w >= W ? w - W : w;
                 const float* pw = slot + w * S::PW;
-                const float wgt = exp2_fast(pw[G * D + (live ? g : 0)] - gm);
-                den = fmaf(wgt, pw[G * D + G + (live ? g : 0)], den);
+                const float wgt = exp2_fast(pw[G * D + g] - gm);
+                den = fmaf(wgt, pw[G * D + G + g], den);
 #pragma unroll
-                for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, pw[(live ? e0 : 0) + x], acc[x]);
+                for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, pw[e0 + x], acc[x]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) {                                         // slot free: count back to zero first, then release
@@ -340,21 +357,23 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __hip_atomic_store(ctl + 1, ord + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (kind == kSegPublish) {
-                float* dst = pubs + (int64_t)share * pubw;
-                if (live) {
+            if (kind == kSegPublish) {                               // every lane: its elements, and m / l of its q head
+                unsigned long long* dst = gran + (int64_t)share * (NG * 64) + lane;
+                const unsigned long long tag = 1ull << 32;
 #pragma unroll
-                    for (int x = 0; x < VEC; ++x) st_agent(dst + e0 + x, acc[x]);
-                    if (d0 == 0) { st_agent(dst + G * D + g, gm); st_agent(dst + G * D + G + g, den); }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of the partial has been acknowledged
-                if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(flags) + share, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int x = 0; x < VEC; ++x)
+                    __hip_atomic_store(dst + x * 64, tag | __builtin_bit_cast(uint32_t, acc[x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + VEC * 64, tag | __builtin_bit_cast(uint32_t, gm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + (VEC + 1) * 64, tag | __builtin_bit_cast(uint32_t, den), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                shstamp<STAMP>(p, wave, 7);
+                ++ord;
                 continue;
             }
             if (kind == kSegMerge) {
                 int spins2 = 0;
-                while (cross_left > 0 && !failed) {
-                    poll_cross();
+                while (cross_left > 0 && !failed) {                 // whatever of the hand-off is still open: now it is waited for
+                    cross_step(true);
+                    if (cstate == 0 && cross_left > 0) __builtin_amdgcn_s_sleep(8);
                     if (++spins2 > kPollLimit) failed = true;
                 }
                 const float nm = fmaxf(cm, gm);
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
 #pragma unroll
                 for (int x = 0; x < VEC; ++x) acc[x] = cacc[x] * wa + acc[x] * wb;
             }
-            if (live) {
+            {
                 const float inv = 1.f / den;
                 uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)(h * G + g) * D + d0;
                 if constexpr (VEC == 1) {
@@ -381,6 +400,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                     }
                 }
             }
+            ++ord;
         }
         if (failed && lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(p.plan) + kHError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); shstamp<STAMP>(p, wave, 5); }
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
 
     // ============================================================================================ streaming wave
     const int j = wave;
-    if (j >= NS) return;
+    if (j >= NS) { __syncthreads(); return; }
     const int Nw = (NS - j + W - 1) / W;                                // this wave's stages: j, j + W, ...
     uint8_t* const wbase = smem + j * S::WAVEB;
     uint8_t* const ringp = wbase;
@@ -402,11 +422,8 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
 
     const int n = lane & 15;                             // q column / K row / d column, by operand
     const int kg = lane >> 4;                            // 16-lane group = k sub-block
-    // dev timing experiments only (wrong results): other head columns than the workgroup's own
-    const int hx = (p.acquire & 4) ? (h + wave) % p.Hkv : h;
-    const int kx = (p.acquire >> 8) & 15, vx = (p.acquire >> 12) & 15;
-    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)(kx ? (kx - 1 + (kx > 8 ? h : 0)) % p.Hkv : hx) * M::ROWB;
-    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)(vx ? (vx - 1 + (vx > 8 ? h : 0)) % p.Hkv : hx) * M::ROWB;
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)h * M::ROWB;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)h * M::ROWB;
     const int64_t row_bytes = p.row_elems * 2;
     const int drow = lane / M::C, dch = lane % M::C;     // DMA: row inside the instruction, chunk position
     int koff[M::NI], voff[M::NI];
@@ -575,21 +592,23 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
         }
     };
 
+    // One stage per wave in flight (eight per CU): measured as fast as two, with half the spread between the waves of
+    // a workgroup, and every wait is a plain vmcnt(0).  The ring has two slots so that stage s+1 can be asked for as
+    // soon as stage s has landed, before it is consumed.
     rec_dma(0);
     rec_dma(1);
+    __syncthreads();                                     // ctl is zero for everyone (nothing reads it before a first flush)
     wait_vmcnt<0>();
     shstamp<STAMP>(p, wave, 2);
+    issue(0);
     for (int s = 0; s < Nw; ++s) {
-        issue(s);
-        wait_vmcnt<S::PER_ITER>();                       // everything but the stage just asked for has landed
-        if (s == 1) shstamp<STAMP>(p, wave, 3);
+        wait_vmcnt<0>();
+        if (s == 0) shstamp<STAMP>(p, wave, 3);
         flush_pend();
-        if (s > 0) consume(s - 1);
+        if (s + 1 < Nw) issue(s + 1);
+        consume(s);
     }
     shstamp<STAMP>(p, wave, 4);
-    wait_vmcnt<0>();
-    flush_pend();
-    consume(Nw - 1);
     flush_pend();
     if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); shstamp<STAMP>(p, wave, 5); }
 }
@@ -630,7 +649,7 @@ int launch_share_plan(const int64_t* seq_lens, const int64_t* rows, const int32_
                       int32_t ps, int32_t Hkv, int32_t D, int32_t G, int64_t cap, int32_t* plan, hipStream_t st) {
     const ShareShape sh = share_shape(Hkv, D, G);
     if (!sh.ok) return M355_ERR_UNSUPPORTED;
-    const ShareLayout L = share_layout(B, sh.nb, Hkv, cap);
+    const ShareLayout L = share_layout(B, sh.nb, Hkv, cap, D, G);
     hipLaunchKernelGGL(share_plan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, sh.nb, Hkv, sh.W, cap, plan, L);
     int64_t blocks = (cap + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -662,11 +681,6 @@ int launch_share_attn(ShareParams& p, int D, int G, bool f16, hipStream_t st, bo
     if (!sh.ok) return M355_ERR_UNSUPPORTED;
     p.nb = sh.nb; p.W = sh.W; p.nslot = sh.nslot;
     p.rot = sh.nb / p.Hkv > 0 ? sh.nb / p.Hkv : 1;
-    { const char* e = getenv("M355_SHARE_ROT"); if (e) p.rot = atoi(e); }                       // dev A/B
-    { const char* e = getenv("M355_SHARE_MIXHEAD"); p.acquire |= (e && atoi(e)) ? 4 : 0; }
-    { const char* e = getenv("M355_SHARE_KCOL"); if (e) p.acquire |= (atoi(e) & 15) << 8; }      // 1..8: all workgroups stream K column e-1; 9..15: own head + e-9
-    { const char* e = getenv("M355_SHARE_VCOL"); if (e) p.acquire |= (atoi(e) & 15) << 12; }
-    { const char* e = getenv("M355_SHARE_EARLY_POLL"); p.acquire |= (e && atoi(e) == 0) ? 2 : 0; }   // dev A/B: bit 1 = poll only at the end
     if (stamp && !f16 && D == 64 && G == 4) {            // dev timing build of the benchmark shape
         static bool allowed = false;
         if (!allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_share_kernel<64, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); allowed = true; }

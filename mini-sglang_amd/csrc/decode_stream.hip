@@ -560,12 +560,7 @@ static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G) {
     if (!sh.ok) return false;
     static const int forced = [] { const char* e = getenv("M355_DECODE_SHARE"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return forced != 0;
-    return false;      // (work in progress: not yet faster than the merge-launch pair on contiguous pools)
     return (int64_t)B * kShareSpan >= sh.nb;
-}
-static int64_t share_pub_bytes(int32_t Hkv, int32_t D, int32_t G) {
-    const ShareShape sh = share_shape(Hkv, D, G);
-    return sh.ok ? (int64_t)Hkv * sh.nb * share_pub_words(D, G) * (int64_t)sizeof(float) : 0;
 }
 
 }  // namespace m355
@@ -580,7 +575,7 @@ extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev-only (n
 extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
     if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
     if (share_mode(B, Hkv, D, G))
-        return share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity).ints * (int64_t)sizeof(int32_t);
+        return share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G).ints * (int64_t)sizeof(int32_t);
     return plan_layout(B, stream_nwh(Hkv, D, G, token_capacity), token_capacity).ints * (int64_t)sizeof(int32_t);
 }
 
@@ -593,7 +588,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
     if (token_capacity > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
     if (share_mode(B, Hkv, D, G)) {
-        const ShareLayout SL = share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity);
+        const ShareLayout SL = share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G);
         if (plan_bytes < SL.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
         return launch_share_plan(seq_lens, page_table_ids, page_table, pt_row_stride, B, page_size, Hkv, D, G, token_capacity,
                                  (int32_t*)plan, (hipStream_t)stream);
@@ -614,7 +609,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
 extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                                        int64_t token_capacity) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return 0;
-    if (share_mode(B, Hkv, D, Hq / Hkv)) return share_pub_bytes(Hkv, D, Hq / Hkv);   // one partial per (share, q head)
+    if (share_mode(B, Hkv, D, Hq / Hkv)) return 0;      // single launch: partials never leave LDS (hand-offs ride in the plan)
     const PlanLayout L = plan_layout(B, stream_nwh(Hkv, D, Hq / Hkv, token_capacity), token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;      // every range boundary and request adds at most one
     return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
@@ -646,7 +641,7 @@ static void launch_stream(const StreamParams& p, hipStream_t st) {
 }
 
 static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
-                                    void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                    int64_t pool_row_stride, void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                     int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
                                     int64_t workspace_bytes, int32_t dtype, void* stream, const void* k_new,
                                     int64_t k_row_stride, const void* v_new, int64_t v_row_stride,
@@ -663,19 +658,19 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
         return M355_ERR_INVALID_ARG;
     if ((q_row_stride % 8) || (o_row_stride % 8) || q_row_stride < (int64_t)Hq * D || o_row_stride < (int64_t)Hq * D)
         return M355_ERR_INVALID_ARG;
+    if (pool_row_stride == 0) pool_row_stride = (int64_t)Hkv * D;
+    if (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8) return M355_ERR_INVALID_ARG;
     if (share_mode(B, Hkv, D, G)) {
         const ShareShape sh = share_shape(Hkv, D, G);
-        const ShareLayout SL = share_layout(B, sh.nb, Hkv, token_capacity);
-        if (!workspace || workspace_bytes < share_pub_bytes(Hkv, D, G) || ((uintptr_t)workspace & 15)) return M355_ERR_WORKSPACE;
+        const ShareLayout SL = share_layout(B, sh.nb, Hkv, token_capacity, D, G);
         ShareParams sp;
         sp.q = (const uint16_t*)q; sp.k_pool = (uint16_t*)k_pool; sp.v_pool = (uint16_t*)v_pool;
         sp.k_new = (const uint16_t*)k_new; sp.v_new = (const uint16_t*)v_new; sp.kn_stride = k_row_stride; sp.vn_stride = v_row_stride;
-        sp.plan = (int32_t*)plan; sp.out = (uint16_t*)out; sp.pub = (float*)workspace;
-        sp.q_stride = q_row_stride; sp.o_stride = o_row_stride; sp.row_elems = (int64_t)Hkv * D;
-        { const char* e = getenv("M355_POOL_PITCH"); if (e) sp.row_elems = atoi(e); }      // dev timing experiment
-        sp.off_share = SL.share; sp.off_flags = SL.flags; sp.off_seg = SL.seg; sp.off_rec = SL.rec;
+        sp.plan = (int32_t*)plan; sp.out = (uint16_t*)out;
+        sp.q_stride = q_row_stride; sp.o_stride = o_row_stride; sp.row_elems = pool_row_stride;
+        sp.off_stg = SL.stg; sp.off_share = SL.share; sp.off_gran = SL.gran; sp.off_rec = SL.rec;
         sp.B = B; sp.Hq = Hq; sp.Hkv = Hkv; sp.scale_log2 = scale * kLog2e;
-        sp.acquire = library_scratch ? 1 : 0;      // a __device__ array is not hipMalloc memory: full acquire after a hand-off poll
+        (void)library_scratch;
         sp.stamps = g_stream_stamps;
         const int rc = launch_share_attn(sp, D, G, f16, (hipStream_t)stream, getenv("M355_STREAM_STAMP") != nullptr);
         return rc != M355_OK ? rc : check_launch();
@@ -690,7 +685,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     p.plan = (const int32_t*)plan; p.out = (uint16_t*)out;
     p.k_new = (const uint16_t*)k_new; p.v_new = (const uint16_t*)v_new; p.kn_stride = k_row_stride; p.vn_stride = v_row_stride;
     p.ws_o = (float*)workspace; p.ws_ml = p.ws_o + n_partials * Hq * D;
-    p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = (int64_t)Hkv * D;
+    p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = pool_row_stride;
     p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_rec = L.rec; p.off_slots = L.slots;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.nwh = nwh; p.max_ranges = L.max_ranges; p.scale_log2 = scale * kLog2e;
     p.stamps = g_stream_stamps;
@@ -713,10 +708,10 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
 }
 
 extern "C" int m355_decode_attn_planned(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
-                                        void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                        int64_t pool_row_stride, void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                         int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void* workspace,
                                         int64_t workspace_bytes, int32_t dtype, void* stream) {
-    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
+    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, pool_row_stride, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     token_capacity, workspace, workspace_bytes, dtype, stream, nullptr, 0, nullptr, 0);
 }
 
@@ -738,7 +733,7 @@ static void* static_scratch() {
 
 extern "C" int m355_decode_store_attn_planned_static(const void* q, int64_t q_row_stride, const void* k_new,
                                                      int64_t k_row_stride, const void* v_new, int64_t v_row_stride,
-                                                     void* k_pool, void* v_pool, void* plan, void* out,
+                                                     void* k_pool, void* v_pool, int64_t pool_row_stride, void* plan, void* out,
                                                      int64_t o_row_stride, int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                                      float scale, int64_t token_capacity, int32_t dtype, void* stream) {
     if (B == 0) return M355_OK;
@@ -751,21 +746,21 @@ extern "C" int m355_decode_store_attn_planned_static(const void* q, int64_t q_ro
     void* ws = static_scratch();
     if (!ws) return M355_ERR_LAUNCH;
     // Nothing in the scratch has to start at zero: every partial the merge reads is written by this same call.
-    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
+    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, pool_row_stride, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     token_capacity, ws, (int64_t)M355_STATIC_SCRATCH_BYTES, dtype, stream, k_new,
                                     k_row_stride, v_new, v_row_stride, /*library_scratch=*/true);
 }
 
 extern "C" int m355_decode_store_attn_planned(const void* q, int64_t q_row_stride, const void* k_new, int64_t k_row_stride,
                                               const void* v_new, int64_t v_row_stride, void* k_pool, void* v_pool,
-                                              void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
+                                              int64_t pool_row_stride, void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                               int32_t Hkv, int32_t D, float scale, int64_t token_capacity,
                                               void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
     if (B == 0) return M355_OK;
     if (!k_new || !v_new || k_row_stride < (int64_t)Hkv * D || v_row_stride < (int64_t)Hkv * D || (k_row_stride % 8) ||
         (v_row_stride % 8) || (((uintptr_t)k_new | (uintptr_t)v_new) & 15))
         return M355_ERR_INVALID_ARG;
-    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
+    return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, pool_row_stride, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     token_capacity, workspace, workspace_bytes, dtype, stream, k_new, k_row_stride, v_new,
                                     v_row_stride);
 }

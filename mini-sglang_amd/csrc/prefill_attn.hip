@@ -741,7 +741,7 @@ extern "C" int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D
 }
 
 extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
-                                 const int32_t* page_table, int64_t pt_row_stride, const int64_t* page_table_ids,
+                                 int64_t pool_row_stride, const int32_t* page_table, int64_t pt_row_stride, const int64_t* page_table_ids,
                                  const int64_t* seq_lens, const int64_t* prefix_lens, const int32_t* cu_q, void* out,
                                  int64_t o_row_stride, int32_t B, int32_t T, int32_t max_extend_len,
                                  int32_t max_seq_len_hint, int32_t Hq, int32_t Hkv, int32_t D, int32_t page_size,
@@ -750,8 +750,10 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     if (!q || !k_pool || !v_pool || !page_table || !out || !seq_lens || !prefix_lens || !cu_q || !page_table_ids || B < 0 ||
         T < 0 || max_extend_len <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || page_size <= 0)
         return M355_ERR_INVALID_ARG;
+    if (pool_row_stride == 0) pool_row_stride = (int64_t)Hkv * D;
+    if (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8) return M355_ERR_INVALID_ARG;
     if (prefill_mode() == 1)        // row-parallel path: every packed query row handled like a decode query
-        return paged_rows_attn(q, q_row_stride, k_pool, v_pool, page_table, pt_row_stride, page_table_ids, nullptr, cu_q,
+        return paged_rows_attn(q, q_row_stride, k_pool, v_pool, pool_row_stride, page_table, pt_row_stride, page_table_ids, nullptr, cu_q,
                                prefix_lens, B, out, o_row_stride, T, Hq, Hkv, D, page_size, scale, max_seq_len_hint,
                                kRowsMaxChunk, workspace, workspace_bytes, dtype, (hipStream_t)stream);
     const bool f16 = dtype == M355_DTYPE_F16;          // IEEE half: the workgroup kernel only
@@ -766,7 +768,7 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     p.q = (const uint16_t*)q; p.k_pool = (const uint16_t*)k_pool; p.v_pool = (const uint16_t*)v_pool;
     p.page_table = page_table; p.page_table_ids = page_table_ids; p.seq_lens = seq_lens; p.prefix_lens = prefix_lens;
     p.cu_q = cu_q; p.out = (uint16_t*)out;
-    p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.pt_stride = pt_row_stride; p.row_elems = (int64_t)Hkv * D;
+    p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.pt_stride = pt_row_stride; p.row_elems = pool_row_stride;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.ps = page_size; p.ps_shift = ilog2_exact_p(page_size);
     p.tiles_max = (max_extend_len * G + 31) / 32;
     p.scale_log2 = scale * kLog2e;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(uint16_t* __restrict
                                                             const float* __restrict__ cache, int64_t max_pos,
                                                             uint16_t* __restrict__ k_pool, uint16_t* __restrict__ v_pool,
                                                             const int64_t* __restrict__ loc, int32_t T, int32_t Hq, int32_t Hkv,
-                                                            int32_t D, int64_t S) {
+                                                            int32_t D, int64_t S, int64_t pool_stride) {
     const int32_t half8 = D / 16;                        // 8-element chunks in half a head
     const int32_t rot_items = (Hq + Hkv) * half8;
     const int32_t v_items = STORE ? Hkv * (D / 8) : 0;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(uint16_t* __restrict
             *reinterpret_cast<u32x4*>(row + D / 2 + c8 * 8) = hi;
             if constexpr (STORE) {
                 if (!is_q && slot_ok) {
-                    uint16_t* dst = k_pool + (slot * Hkv + (head - Hq)) * D;
+                    uint16_t* dst = k_pool + slot * pool_stride + (int64_t)(head - Hq) * D;
                     *reinterpret_cast<u32x4*>(dst + c8 * 8) = lo;
                     *reinterpret_cast<u32x4*>(dst + D / 2 + c8 * 8) = hi;
                 }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(uint16_t* __restrict
         } else if constexpr (STORE) {
             const int32_t c = j - rot_items;                                    // 16-byte chunk of the v row
             if (slot_ok)
-                *reinterpret_cast<u32x4*>(v_pool + slot * (int64_t)Hkv * D + (int64_t)c * 8) =
+                *reinterpret_cast<u32x4*>(v_pool + slot * pool_stride + (int64_t)c * 8) =
                     *reinterpret_cast<const u32x4*>(v + t * v_stride + (int64_t)c * 8);
         }
     }
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(uint16_t* __restrict
 
 extern "C" int m355_rope_kv_store(void* q, int64_t q_row_stride, void* k, int64_t k_row_stride, const void* v,
                                   int64_t v_row_stride, const int64_t* positions, const float* cos_sin_cache,
-                                  int64_t max_position, void* k_pool, void* v_pool, const int64_t* loc, int32_t T,
-                                  int32_t Hq, int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void* stream) {
+                                  int64_t max_position, void* k_pool, void* v_pool, int64_t pool_row_stride, const int64_t* loc,
+                                  int32_t T, int32_t Hq, int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void* stream) {
     if (T == 0) return M355_OK;
     if (!q || !k || !positions || !cos_sin_cache || T < 0 || Hq <= 0 || Hkv <= 0 || max_position <= 0) return M355_ERR_INVALID_ARG;
     const bool store = k_pool != nullptr;
@@ -103,6 +103,8 @@ extern "C" int m355_rope_kv_store(void* q, int64_t q_row_stride, void* k, int64_
     if (D <= 0 || D % 16) return M355_ERR_UNSUPPORTED;
     if (q_row_stride < (int64_t)Hq * D || k_row_stride < (int64_t)Hkv * D || q_row_stride % 8 || k_row_stride % 8) return M355_ERR_INVALID_ARG;
     if (store && (v_row_stride < (int64_t)Hkv * D || v_row_stride % 8)) return M355_ERR_INVALID_ARG;
+    if (pool_row_stride == 0) pool_row_stride = (int64_t)Hkv * D;
+    if (store && (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8)) return M355_ERR_INVALID_ARG;
     uintptr_t bits = (uintptr_t)q | (uintptr_t)k | (uintptr_t)cos_sin_cache;
     if (store) bits |= (uintptr_t)v | (uintptr_t)k_pool | (uintptr_t)v_pool;
     if (bits & 15) return M355_ERR_INVALID_ARG;
@@ -113,22 +115,22 @@ extern "C" int m355_rope_kv_store(void* q, int64_t q_row_stride, void* k, int64_
         if (store)
             hipLaunchKernelGGL((m355::rope_kv_store_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                                (uint16_t*)q, q_row_stride, (uint16_t*)k, k_row_stride, (const uint16_t*)v, v_row_stride, positions,
-                               cos_sin_cache, max_position, (uint16_t*)k_pool, (uint16_t*)v_pool, loc, T, Hq, Hkv, D, S);
+                               cos_sin_cache, max_position, (uint16_t*)k_pool, (uint16_t*)v_pool, loc, T, Hq, Hkv, D, S, pool_row_stride);
         else
             hipLaunchKernelGGL((m355::rope_kv_store_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                                (uint16_t*)q, q_row_stride, (uint16_t*)k, k_row_stride, (const uint16_t*)nullptr, (int64_t)0, positions,
                                cos_sin_cache, max_position, (uint16_t*)nullptr, (uint16_t*)nullptr, (const int64_t*)nullptr, T, Hq, Hkv,
-                               D, (int64_t)0);
+                               D, (int64_t)0, (int64_t)0);
         return m355::check_launch();
     }
     if (store)
         hipLaunchKernelGGL(m355::rope_kv_store_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (uint16_t*)q, q_row_stride, (uint16_t*)k, k_row_stride, (const uint16_t*)v, v_row_stride, positions,
-                           cos_sin_cache, max_position, (uint16_t*)k_pool, (uint16_t*)v_pool, loc, T, Hq, Hkv, D, S);
+                           cos_sin_cache, max_position, (uint16_t*)k_pool, (uint16_t*)v_pool, loc, T, Hq, Hkv, D, S, pool_row_stride);
     else
         hipLaunchKernelGGL(m355::rope_kv_store_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (uint16_t*)q, q_row_stride, (uint16_t*)k, k_row_stride, (const uint16_t*)nullptr, (int64_t)0, positions,
                            cos_sin_cache, max_position, (uint16_t*)nullptr, (uint16_t*)nullptr, (const int64_t*)nullptr, T, Hq, Hkv,
-                           D, (int64_t)0);
+                           D, (int64_t)0, (int64_t)0);
     return m355::check_launch();
 }

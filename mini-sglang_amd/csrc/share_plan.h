@@ -14,32 +14,33 @@ constexpr int kRecFirst = 1 << 8;               // meta flag: the owning wave's 
 constexpr int kRecLast = 1 << 9;                // meta flag: the owning wave's last stage of this segment
 constexpr int kRecNewest = 1 << 10;             // meta flag: token valid-1 of the stage is the request's newest token
 constexpr int kShareHdr = 16;                   // plan header words
-constexpr int kShareW = 8;                      // words per share entry: {stages, first stage, first segment, segments, ...}
-constexpr int kSegW = 4;                        // words per segment entry: {request, stages, kind, first share of the request}
-constexpr int kSegWhole = 0, kSegPublish = 1, kSegMerge = 2;
-constexpr int kShareMinTok = 128;               // shortest share
+constexpr int kShareW = 8;                      // words per share entry: {first request, last request, ...}
+constexpr int kSegWhole = 0, kSegPublish = 1, kSegMerge = 2;     // a segment = one request's stages inside one share
+constexpr int kShareMinStages = 4;              // shortest share
 constexpr int kShareMaxWaves = 8;               // streaming waves per workgroup (plus one finishing wave)
 constexpr int kShareCumLds = 4096;              // requests whose prefix sums the plan kernels stage in LDS
 
 // header words
-constexpr int kHTotal = 0, kHShareTok = 1, kHB = 2, kHShares = 3, kHWaves = 4, kHStages = 5, kHError = 6;
+constexpr int kHTotal = 0, kHShareStages = 1, kHB = 2, kHShares = 3, kHWaves = 4, kHStages = 5, kHError = 6;
 
-// plan buffer (int32 words): hdr | cum[B+1] | stg[B+1] | nz[B+1] | share[nb][kShareW] | flags[Hkv*nb] | seg[(B+nb)][kSegW] |
-//                            rec[max_stages][kRecW]
+// hand-off granules per (kv head, share): one fp32 partial O[G][D] + m, l per lane, 8 bytes {value, tag} each
+__host__ __device__ inline int64_t share_gran_words(int D, int G) { return (int64_t)((G * D / 64 > 0 ? G * D / 64 : 1) + 2) * 64 * 2; }
+
+// plan buffer (int32 words): hdr | cum[B+1] | stg[B+1] | nz[B+1] | share[nb][kShareW] | gran[Hkv*nb][...] | rec[max_stages][kRecW]
 struct ShareLayout {
-    int64_t cum, stg, nz, share, flags, seg, rec, ints;
+    int64_t cum, stg, nz, share, gran, gran_words, rec, ints;
     int64_t max_stages;
 };
-__host__ __device__ inline ShareLayout share_layout(int32_t B, int32_t nb, int32_t Hkv, int64_t cap) {
+__host__ __device__ inline ShareLayout share_layout(int32_t B, int32_t nb, int32_t Hkv, int64_t cap, int32_t D, int32_t G) {
     ShareLayout L;
-    L.max_stages = cap / kStageTok + B + nb + 2;
+    L.max_stages = cap / kStageTok + B + 2;         // every request adds at most one partial stage
     L.cum = kShareHdr;
     L.stg = L.cum + (B + 1);
     L.nz = L.stg + (B + 1);
     L.share = (L.nz + (B + 1) + 3) & ~(int64_t)3;
-    L.flags = L.share + (int64_t)nb * kShareW;
-    L.seg = (L.flags + (int64_t)Hkv * nb + 3) & ~(int64_t)3;
-    L.rec = (L.seg + (int64_t)(B + nb) * kSegW + 63) & ~(int64_t)63;       // records start on a 256-byte line
+    L.gran = (L.share + (int64_t)nb * kShareW + 63) & ~(int64_t)63;
+    L.gran_words = (int64_t)Hkv * nb * share_gran_words(D, G);
+    L.rec = (L.gran + L.gran_words + 63) & ~(int64_t)63;                   // records start on a 256-byte line
     L.ints = L.rec + L.max_stages * kRecW;
     return L;
 }
@@ -50,8 +51,6 @@ struct ShareShape {
     bool ok;
 };
 ShareShape share_shape(int Hkv, int D, int G);
-// published share partial (fp32 words, a multiple of 64): O[G][D], m[G], l[G]
-__host__ __device__ inline int share_pub_words(int D, int G) { return (G * (D + 2) + 63) / 64 * 64; }
 
 struct ShareParams {
     const uint16_t* q;
@@ -60,14 +59,12 @@ struct ShareParams {
     const uint16_t* k_new;        // fused KV store: the step's new K/V rows [B, Hkv*D], or nullptr
     const uint16_t* v_new;
     int64_t kn_stride, vn_stride;
-    int32_t* plan;                // the kernel raises and clears the hand-off flags inside it
+    int32_t* plan;                // the kernel raises and lowers the hand-off granules inside it
     uint16_t* out;
-    float* pub;                   // [Hkv][nb][share_pub_words]: share partials of requests cut by a share boundary
     int64_t q_stride, o_stride, row_elems;
-    int64_t off_share, off_flags, off_seg, off_rec;
+    int64_t off_stg, off_share, off_gran, off_rec;
     int32_t B, Hq, Hkv, nb, W, nslot, rot;
     float scale_log2;
-    int32_t acquire;              // 1: agent acquire after a hand-off poll (pub is not hipMalloc memory: the static scratch)
     unsigned long long* stamps;   // dev-only timing probe (tools/stamp_share.py), 8 slots per wave; else nullptr
 };
 

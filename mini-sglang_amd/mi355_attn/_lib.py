@@ -17,7 +17,7 @@ DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 SIGNATURES = {
     "m355_version": (c_int32, []),
     "m355_strerror": (c_char_p, [c_int32]),
-    "m355_kv_store": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
+    "m355_kv_store": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
                                 c_int32, c_int32, c_int64, c_int32, c_void_p]),
     "m355_out_cache_loc": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "m355_prefill_prepare": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
@@ -30,29 +30,29 @@ SIGNATURES = {
     "m355_decode_prepare_ring": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                            c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "m355_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
-    "m355_decode_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+    "m355_decode_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
                                    c_int32, c_void_p, c_int64, c_int32, c_void_p]),
     "m355_decode_plan_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
     "m355_decode_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int64, c_void_p, c_int64, c_void_p]),
     "m355_decode_planned_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
-    "m355_decode_attn_planned": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+    "m355_decode_attn_planned": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                            c_int32, c_int32, c_int32, c_float, c_int64, c_void_p, c_int64, c_int32,
                                            c_void_p]),
     "m355_decode_store_attn_planned": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                                                 c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_float,
+                                                 c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_float,
                                                  c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     "m355_decode_store_attn_planned_static": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
-                                                        c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                                        c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                                         c_int32, c_float, c_int64, c_int32, c_void_p]),
     "m355_prefill_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
-    "m355_prefill_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+    "m355_prefill_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_int32,
                                     c_void_p]),
     "m355_rope_kv_store": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                                     c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                      c_int64, c_int32, c_void_p]),
 }
 

@@ -1,9 +1,18 @@
 """KV pools + free-page FIFO with the reference's interface (memory/kvcache.py:5-91).
 
 Differences that do not change results: all layers' K and V pools are carved from ONE HBM allocation
-([layer, K|V, S, Hkv, D]; `k_cache[l]` / `v_cache[l]` are views with the reference's [S, Hkv, D] shape), the
+([layer, K|V, S, row pitch]; `k_cache[l]` / `v_cache[l]` are views with the reference's [S, Hkv, D] shape), the
 free list is a deque (O(1) pops instead of list slicing), and `write_kv` is the HIP row scatter instead of
 two `index_put_` launches.
+
+Row pitch: a token row of the reference's contiguous [S, Hkv, D] pool is Hkv*D*2 bytes - a power of two for every
+Llama shape - so one kv head's K (or V) bytes of ALL tokens sit in one fixed 128/256-byte column: fixed address bits
+7..9.  The decode kernel gives a CU one kv head to stream, and on MI355X a CU whose every request hits one such
+column runs up to 30 % slower on some columns (tools/stamp_share.py).  With `row_pad` elements of
+padding per row (default: 128 bytes when a row is >= 1 KiB, i.e. <= 12.5 % of the pool) the pitch is an odd number of
+128-byte lines and every head's column walks through all eight patterns as the slot number grows.  The views keep the
+reference's shape and indexing; only `stride(0)` differs, and every entry point of the library takes that pitch
+(`pool_row_stride`).  `row_pad=0` gives the reference's contiguous layout.
 """
 from __future__ import annotations
 
@@ -17,7 +26,7 @@ from . import ops
 
 class KVCache:
     def __init__(self, size: int, page_size: int, head_num: int, head_dim: int, dtype: torch.dtype,
-                 layer_num: int, device: str, device_free_list: bool = False):
+                 layer_num: int, device: str, device_free_list: bool = False, row_pad: Optional[int] = None):
         self.page_num = size // page_size                                   # kvcache.py:16
         self.page_size = page_size
         self.head_num = head_num
@@ -26,9 +35,17 @@ class KVCache:
         self.layer_num = layer_num
         self.device = device
         rows = self.page_num * page_size
-        self._store = torch.zeros((layer_num, 2, rows, head_num, head_dim), dtype=dtype, device=device)
-        self.k_cache = [self._store[l, 0] for l in range(layer_num)]        # kvcache.py:24-35 shapes
-        self.v_cache = [self._store[l, 1] for l in range(layer_num)]
+        width = head_num * head_dim
+        esize = torch.empty((), dtype=dtype).element_size()
+        if row_pad is None:                                                 # 128 bytes per row where that costs <= 12.5 %
+            row_pad = 128 // esize if width * esize >= 1024 and (width * esize) % 256 == 0 else 0
+        if row_pad < 0 or (row_pad * esize) % 16:
+            raise ValueError("row_pad must be a whole number of 16-byte chunks")
+        self.row_pitch = width + row_pad                                    # elements between consecutive token rows
+        self._store = torch.zeros((layer_num, 2, rows, self.row_pitch), dtype=dtype, device=device)
+        # the reference's [S, Hkv, D] tensors (kvcache.py:24-35), as views into the padded rows
+        self.k_cache = [self._store[l, 0, :, :width].unflatten(1, (head_num, head_dim)) for l in range(layer_num)]
+        self.v_cache = [self._store[l, 1, :, :width].unflatten(1, (head_num, head_dim)) for l in range(layer_num)]
         # optional device mirror of the FIFO: decode steps then allocate inside their metadata kernel
         self.ring = ops.PageRing(self.page_num, device) if device_free_list else None
         self._ring_defer = None                    # pops batched into one launch while a prefill allocates

@@ -14,6 +14,19 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def pool_pitch(k_pool: torch.Tensor, v_pool: torch.Tensor) -> int:
+    """Row pitch (elements) of a pair of [S, Hkv, D] pools: dense inside a token row, any pitch >= Hkv*D between rows
+    (the reference's tensors are contiguous, memory/kvcache.py:24-35; mi355_attn.KVCache pads its rows)."""
+    S, Hkv, D = k_pool.shape
+    for t in (k_pool, v_pool):
+        if t.shape != k_pool.shape or t.stride(2) != 1 or t.stride(1) != D or (S > 1 and t.stride(0) != k_pool.stride(0)):
+            raise _lib.MI355AttnError("KV pools must be [S, Hkv, D], dense inside a row, K and V with the same row pitch")
+    pitch = k_pool.stride(0) if S > 1 else Hkv * D
+    if pitch < Hkv * D or pitch % 8:
+        raise _lib.MI355AttnError(f"KV pool row pitch {pitch} must be a multiple of 8 elements and >= Hkv*D")
+    return pitch
+
+
 def kv_store(k_pool: torch.Tensor, v_pool: torch.Tensor, loc: torch.Tensor, k_src: torch.Tensor,
              v_src: torch.Tensor) -> None:
     """k_pool[loc] = k_src; v_pool[loc] = v_src  (reference memory/kvcache.py:69-79).
@@ -33,9 +46,9 @@ def kv_store(k_pool: torch.Tensor, v_pool: torch.Tensor, loc: torch.Tensor, k_sr
         raise _lib.MI355AttnError("kv_store: source rows must have inner stride 1")
     if loc.dtype != torch.int64:
         raise _lib.MI355AttnError("kv_store: loc must be int64")
-    if not (k_pool.is_contiguous() and v_pool.is_contiguous() and loc.is_contiguous()):
-        raise _lib.MI355AttnError("kv_store: pools and loc must be contiguous")
-    check(lib.m355_kv_store(k_pool.data_ptr(), v_pool.data_ptr(), k2.data_ptr(), v2.data_ptr(),
+    if not loc.is_contiguous():
+        raise _lib.MI355AttnError("kv_store: loc must be contiguous")
+    check(lib.m355_kv_store(k_pool.data_ptr(), v_pool.data_ptr(), pool_pitch(k_pool, v_pool), k2.data_ptr(), v2.data_ptr(),
                             k2.stride(0) if T else Hkv * D, v2.stride(0) if T else Hkv * D, loc.data_ptr(), T, Hkv, D,
                             S, dtype_code(k_pool.dtype), current_stream()), "m355_kv_store")
 
@@ -186,7 +199,8 @@ def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, pag
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     assert page_table.dtype == torch.int32 and page_table_ids.dtype == torch.int64 and seq_lens.dtype == torch.int64
-    check(lib.m355_decode_attn(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), page_table.data_ptr(),
+    check(lib.m355_decode_attn(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), pool_pitch(k_pool, v_pool),
+                               page_table.data_ptr(),
                                page_table.stride(0), page_table_ids.data_ptr(), seq_lens.data_ptr(), out.data_ptr(),
                                out.stride(0), B, Hq, Hkv, D, page_size, scale, max_seq_len, chunk_tokens,
                                _ptr(workspace), ws_bytes, dtype_code(q.dtype), current_stream()), "m355_decode_attn")
@@ -242,6 +256,7 @@ def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Ten
     B, Hq = q.shape[0], num_heads
     if (B, Hkv, D, Hq // Hkv) != (plan.B, plan.Hkv, plan.D, plan.G):
         raise _lib.MI355AttnError("decode_attn_planned: plan was built for a different batch or head shape")
+    pitch = pool_pitch(k_pool, v_pool)
     q2 = q.view(B, Hq * D)
     if q2.stride(1) != 1:
         q2 = q2.contiguous()
@@ -262,17 +277,17 @@ def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Ten
         if static_scratch:
             check(lib.m355_decode_store_attn_planned_static(q2.data_ptr(), q2.stride(0), k2.data_ptr(), k2.stride(0),
                                                             v2.data_ptr(), v2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(),
-                                                            plan.buf.data_ptr(), out.data_ptr(), out.stride(0), B, Hq, Hkv, D,
+                                                            pitch, plan.buf.data_ptr(), out.data_ptr(), out.stride(0), B, Hq, Hkv, D,
                                                             scale, plan.capacity, dtype_code(q.dtype), current_stream()),
                   "m355_decode_store_attn_planned_static")
             return out
         check(lib.m355_decode_store_attn_planned(q2.data_ptr(), q2.stride(0), k2.data_ptr(), k2.stride(0), v2.data_ptr(),
-                                                 v2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), plan.buf.data_ptr(),
+                                                 v2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), pitch, plan.buf.data_ptr(),
                                                  out.data_ptr(), out.stride(0), B, Hq, Hkv, D, scale, plan.capacity,
                                                  workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                                  dtype_code(q.dtype), current_stream()), "m355_decode_store_attn_planned")
         return out
-    check(lib.m355_decode_attn_planned(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(),
+    check(lib.m355_decode_attn_planned(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), pitch,
                                        plan.buf.data_ptr(), out.data_ptr(), out.stride(0), B, Hq, Hkv, D, scale,
                                        plan.capacity, workspace.data_ptr(),
                                        workspace.numel() * workspace.element_size(), dtype_code(q.dtype),
@@ -311,7 +326,7 @@ def prefill_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, pa
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     assert cu_q.dtype == torch.int32 and prefix_lens.dtype == torch.int64
-    check(lib.m355_prefill_attn(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(),
+    check(lib.m355_prefill_attn(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), pool_pitch(k_pool, v_pool),
                                 page_table.data_ptr(), page_table.stride(0), page_table_ids.data_ptr(),
                                 seq_lens.data_ptr(), prefix_lens.data_ptr(), cu_q.data_ptr(), out.data_ptr(),
                                 out.stride(0), B, T, max_extend_len, max_seq_len, Hq, Hkv, D, page_size, scale,
@@ -344,10 +359,11 @@ def rope_kv_store(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, hea
     if store:
         S = k_pool.shape[0]
         if v.dim() != 2 or (T and v.stride(1) != 1) or loc.dtype != torch.int64 or not loc.is_contiguous() \
-                or not (k_pool.is_contiguous() and v_pool.is_contiguous()) or k_pool.dtype != k.dtype:
-            raise _lib.MI355AttnError("rope_kv_store: v [T, Hkv*D] inner stride 1, loc int64, contiguous pools of k's dtype")
+                or k_pool.dtype != k.dtype:
+            raise _lib.MI355AttnError("rope_kv_store: v [T, Hkv*D] inner stride 1, loc int64, pools of k's dtype")
     check(lib.m355_rope_kv_store(q.data_ptr(), q.stride(0) if T else Hq * D, k.data_ptr(), k.stride(0) if T else Hkv * D,
                                  _ptr(v) if store else None, (v.stride(0) if T else Hkv * D) if store else 0,
                                  positions.data_ptr(), cos_sin_cache.data_ptr(), cos_sin_cache.shape[0],
-                                 _ptr(k_pool), _ptr(v_pool), _ptr(loc) if store else None, T, Hq, Hkv, D, S,
+                                 _ptr(k_pool), _ptr(v_pool), pool_pitch(k_pool, v_pool) if store else 0,
+                                 _ptr(loc) if store else None, T, Hq, Hkv, D, S,
                                  dtype_code(q.dtype), current_stream()), "m355_rope_kv_store")

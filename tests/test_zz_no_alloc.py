@@ -44,7 +44,7 @@ def _run_both(ops, lib, B, Hq, Hkv, D, ps, lens, seed):
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
     o1 = torch.full((B, Hq * D), 7.0, dtype=torch.bfloat16, device=DEV)
     rc = lib.m355_decode_store_attn_planned(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                            kp1.data_ptr(), vp1.data_ptr(), plan.buf.data_ptr(), o1.data_ptr(), o1.stride(0),
+                                            kp1.data_ptr(), vp1.data_ptr(), 0, plan.buf.data_ptr(), o1.data_ptr(), o1.stride(0),
                                             B, Hq, Hkv, D, D ** -0.5, cap, ws.data_ptr(), need, 0, current_stream())
     assert rc == 0
     # allocation-free form: every buffer it touches exists before the call
@@ -53,7 +53,7 @@ def _run_both(ops, lib, B, Hq, Hkv, D, ps, lens, seed):
     torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
     rc = lib.m355_decode_store_attn_planned_static(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
-                                                   v.stride(0), kp2.data_ptr(), vp2.data_ptr(), plan.buf.data_ptr(),
+                                                   v.stride(0), kp2.data_ptr(), vp2.data_ptr(), 0, plan.buf.data_ptr(),
                                                    o2.data_ptr(), o2.stride(0), B, Hq, Hkv, D, D ** -0.5, cap, 0,
                                                    current_stream())
     assert rc == 0
@@ -98,7 +98,7 @@ def test_static_scratch_entry_refuses_what_does_not_fit():
     assert lib.m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap) > ops.STATIC_SCRATCH_BYTES
     x = torch.zeros(4096, dtype=torch.bfloat16, device=DEV)       # any valid, aligned device pointer: nothing is launched
     rc = lib.m355_decode_store_attn_planned_static(x.data_ptr(), Hq * D, x.data_ptr(), Hkv * D, x.data_ptr(), Hkv * D,
-                                                   x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), Hq * D, B, Hq,
+                                                   x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), x.data_ptr(), Hq * D, B, Hq,
                                                    Hkv, D, 0.1, cap, 0, None)
     assert rc == -5
     assert b"M355_STATIC_SCRATCH_BYTES" in lib.m355_strerror(rc)

@@ -26,7 +26,7 @@ random.seed(0)
 lens = [random.randint(64, 2048) + 1 for _ in range(64)]
 B = len(lens)
 pages = sum(-(-l // ps) for l in lens) + 8
-kv = m.KVCache(pages * ps * (2 if os.environ.get('M355_POOL_PITCH') else 1), ps, Hkv, D, torch.bfloat16, L, dev)
+kv = m.KVCache(pages * ps, ps, Hkv, D, torch.bfloat16, L, dev, row_pad=int(os.environ['ROW_PAD']) if 'ROW_PAD' in os.environ else None)
 pm = m.PageManager(ps, B, 4096, dev)
 kv._free = deque(torch.randperm(pages, generator=torch.Generator().manual_seed(0)).tolist())
 kv._store.copy_(torch.randn(kv._store.shape, device=dev).to(torch.bfloat16))
@@ -78,7 +78,7 @@ print(f"finishing wave: last arrival -> done: median {us(np.median(tail)):.2f} p
 loop = st[:, 4] - st[:, 3]
 print(f"streaming loop (first stage landed -> last issued): median {us(np.median(loop)):.2f} p95 {us(np.percentile(loop,95)):.2f} max {us(loop.max()):.2f}")
 hdr = plan.buf.view(torch.int32)[:8].cpu().numpy()
-print("plan header: total", hdr[0], "share tokens", hdr[1], "shares", hdr[3], "waves", hdr[4], "stages", hdr[5], "error", hdr[6])
+print("plan header: total", hdr[0], "share stages", hdr[1], "shares", hdr[3], "waves", hdr[4], "stages", hdr[5], "error", hdr[6])
 # ---- where does the spread come from: wave index, XCD slot, workgroup
 S5 = (s[:, :8, 5] - t0) * 0.01
 S3 = (s[:, :8, 3] - t0) * 0.01
@@ -108,3 +108,30 @@ LOOP = (s[:, :8, 4] - s[:, :8, 3]) * 0.01
 for h_ in range(8):
     sel = head == h_
     print(f"  h={h_}: {np.median(wg_end[sel]):6.2f} / {wg_end[sel].max():6.2f}   loop {np.median(LOOP[sel]):6.2f}   first {np.median(S3[sel]):5.2f}")
+late = hp[:, 3] > hp[:, 4]
+has = hp[:, 3] > 0
+print(f"hand-off complete AFTER the last arrival in {int((late & has).sum())} of {int(has.sum())} merging workgroups; "
+      f"when late, by median {us(np.median((hp[late & has, 3] - hp[late & has, 4]))) if (late & has).any() else 0:.2f} us")
+ok = has & ~late
+if ok.any():
+    print(f"tail when the hand-off was complete in time: median {us(np.median(tail[ok])):.2f} max {us(tail[ok].max()):.2f}; no hand-off at all: "
+          f"{us(np.median(tail[~has])) if (~has).any() else 0:.2f}")
+first_seg = (hp[:, 2] - t0) * 0.01
+print("first segment complete (publishers publish then): percentiles", [round(float(np.percentile(first_seg, q)), 1) for q in (5, 25, 50, 75, 95)])
+# publisher (share i-1, head h) first segment done  vs  merger (share i, head h) hand-off complete
+blk = np.arange(nblocks)
+share_of = blk // 8
+hp_all = s[:, 8]
+idx = {(int(share_of[b]), int(head[b])): b for b in blk}
+gaps = []
+for b in blk:
+    i_, h_ = int(share_of[b]), int(head[b])
+    if i_ == 0 or hp_all[b, 3] == 0:
+        continue
+    pb = idx[(i_ - 1, h_)]
+    gaps.append(((hp_all[b, 3] - hp_all[pb, 2]) * 0.01, (hp_all[pb, 2] - t0) * 0.01, (hp_all[b, 3] - t0) * 0.01, (hp_all[b, 4] - t0) * 0.01,
+                 (hp_all[pb, 7] - t0) * 0.01, (hp_all[b, 6] - t0) * 0.01))
+gaps = np.array(gaps)
+print("publisher first-segment-done -> merger hand-off complete: median %.2f p5 %.2f p95 %.2f" % (np.median(gaps[:, 0]), np.percentile(gaps[:, 0], 5), np.percentile(gaps[:, 0], 95)))
+for r in gaps[:12]:
+    print("   pub done %.1f  granules stored %.1f  merger saw them %.1f  merger complete %.1f  merger last arrival %.1f" % (r[1], r[4], r[5], r[2], r[3]))
