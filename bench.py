@@ -1,39 +1,47 @@
 #!/usr/bin/env python3
-"""bench.py - decode-attention hot path on MI355X (BASELINE.json configs[1]).
+"""bench.py - decode-attention hot path on MI355X (BASELINE.json configs[1]) + the rest of BASELINE's metric.
 
-Workload at N=1: Llama-3.2-1B head shape (Hq=32, Hkv=8, D=64, 16 layers), batch 64 with ragged lengths
+`python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).  With N > 1 and no WORLD_SIZE in the
+environment it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a child process -
+before anything touches the GPU - and relays the child's line (the reference spawns its TP ranks itself too,
+bench_one_batch.py:275-292); launched by torch.distributed.run it is one rank per GPU over RCCL.
+
+Workload of `value` at N=1: Llama-3.2-1B head shape (Hq=32, Hkv=8, D=64, 16 layers), batch 64 with ragged lengths
 `random.seed(0); randint(64, 2048)` (sum 73 961), page_size 16, physical pages handed out in shuffled order,
 distinct K/V pools per layer (2.4 GB: nothing is served from the 256 MiB Infinity Cache).
 
 One STEP = one decode step of the hot path over the whole batch: Batch.prepare_for_decode (host plan + the
-m355_decode_prepare kernel) and then, for each of the 16 layers, the KV slot write (m355_kv_store) and paged
-decode attention (m355_decode_attn).  `value` = algorithmic HBM bytes of the attention path per step / step
-time, summed over ranks (bytes_all = 4*Hkv*D*sum(L) + 4*B*Hq*D + 4*sum(ceil(L/ps)) + 16*B per
-layer, plus the kv_store bytes).  Inputs are resident in HBM before the timed region.
+metadata kernel) and then, for each of the 16 layers, the KV slot write and paged decode attention (one fused
+launch, m355_decode_store_attn_planned).  `value` = algorithmic HBM bytes of the attention path per step / step time,
+summed over ranks (bytes_all = 4*Hkv*D*sum(L) + 4*B*Hq*D + 4*sum(ceil(L/ps)) + 16*B per layer, plus
+the kv_store bytes).  Inputs are resident in HBM before the timed region.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): the reference's tensor parallelism - every rank
-owns Hq/N query heads and Hkv/N kv heads of EVERY sequence (models/llama.py:76-87) - with the global batch
-grown to 64*N so per-GPU bytes stay fixed ("weak").  The attention path has no exchange step:
-the timed steps contain no collective.  The one collective of the surrounding layer - the RCCL all-reduce of the
-[B_global, hidden] bf16 o_proj output (layers/linear.py:228-232) - is timed SEPARATELY after the main
-measurement and reported as `allreduce_o_proj`, not folded into `value`.
+N>1: the reference's tensor parallelism - every rank owns Hq/N query heads and Hkv/N kv heads of EVERY sequence
+(models/llama.py:76-87) - with the global batch grown to 64*N so per-GPU bytes stay fixed ("weak").  The attention path
+has no exchange step: the timed steps contain no collective.  The one collective of the surrounding
+layer - the RCCL all-reduce of the o_proj output (layers/linear.py:228-232) - is timed separately and reported beside.
 
-`roofline`: the decode launches alone, exactly as the steps make them (decode_mfma_kernel with the fused KV
-store + stream_merge_kernel; M355_BENCH_ROOFLINE_FUSED=0 times the attention-only launch instead), HIP-event
-timed over all layers back to back, against 8.0 TB/s - so the rocprofv3 averages of the same command
-(profiles/rNN_bench_kernel_stats.csv: main + merge) add up to `us_per_launch`.  `cpu_baseline`: the oracle (torch-native algorithm restated in
-oracle/attention_ref.py) on the host cores for one layer of the same batch, rank 0, N=1 only.
+`roofline`: the decode launches alone, exactly as the steps make them, HIP-event timed over all layers back to back,
+against 8.0 TB/s; the rocprofv3 average of the same command is profiles/rNN_bench_kernel_stats.csv.
+`cpu_baseline`: the oracle (torch-native algorithm restated in oracle/attention_ref.py) on the host cores for one layer
+of the same batch, rank 0, N=1 only.
+
+`extras` (side measurements in the same run, each named; --no-extras skips them):
+  N=1  decode_8b_shape, decode_cfg5_per_rank (70B/TP8 per-rank shape, 32k context, B = 1/8/32), prefill_cfg3,
+       bench_one_batch_llama3_8b (eager and --graph), cpu_baseline_cfg1
+  N>1  bench_one_batch_llama3_8b at TP=N, prefill_cfg3_per_rank, decode_cfg5_per_rank (N=8), the o_proj all-reduce legs
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
-import random
+import socket
+import statistics
+import subprocess
 import sys
 import time
-from collections import deque
-from types import SimpleNamespace
 
 import torch
 import torch.distributed as dist
@@ -43,27 +51,18 @@ for p in (REPO, os.path.join(REPO, "mini-sglang_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MODEL = dict(name="Llama-3.2-1B", layers=16, hidden=2048, Hq=32, Hkv=8, D=64)
 PAGE_SIZE = 16
 
 
-def cfg2_lengths(n_copies: int):
-    lens = []
-    for c in range(n_copies):
-        random.seed(c)              # copy 0 is exactly the BASELINE list (seed 0)
-        lens += [random.randint(64, 2048) for _ in range(64)]
-    return lens
-
-
-def attn_bytes_per_layer(lens, Hq, Hkv, D, ps):
-    B = len(lens)
-    kv = 4 * Hkv * D * sum(lens)
-    return kv + 4 * B * Hq * D + 4 * sum(-(-l // ps) for l in lens) + 16 * B
-
-
-def kv_store_bytes_per_layer(T, Hkv, D):
-    return 8 * T * Hkv * D + 8 * T
+def self_launch(args) -> int:
+    """N > 1 without a launcher: become the launcher.  Nothing in this process has touched the GPU yet."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -72,7 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chunk", type=int, default=-1, help="decode chunk tokens override (-1: backend heuristic)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling passes)")
     ap.add_argument("--heads", type=str, default="", help="experiment: Hq,Hkv,D per GPU instead of the 1B shape")
     ap.add_argument("--copies", type=int, default=0, help="experiment: batch = 64 * copies")
     ap.add_argument("--fixed-len", type=int, default=0, help="experiment: every request has this length (with --batch)")
@@ -81,13 +80,12 @@ def main():
     ap.add_argument("--len-scale", type=int, default=1, help="experiment: every length x this (SURVEY 8d cfg2 'long' variant: 8)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
     rehearse = os.environ.get("M355_BENCH_REHEARSE") == "1"            # dev: all ranks on cuda:0 over gloo (one-GPU box)
     if rehearse:
         local_rank = 0
@@ -99,18 +97,17 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))     # RCCL over xGMI
 
-    import mi355_attn as m
-    from mi355_attn import ops
-
-    from mi355_attn.tp import all_reduce_rows, row_parallel_linear, shard_heads
+    from harness import workloads as W
+    from mi355_attn.tp import shard_heads
 
     tp = world
     shard = shard_heads(MODEL["Hq"], MODEL["Hkv"], MODEL["D"], tp, rank)    # refuses tp > num_kv_heads
-    Hq, Hkv, D, L, hidden = shard.num_heads, shard.num_kv_heads, MODEL["D"], MODEL["layers"], MODEL["hidden"]
+    Hq, Hkv, D, L = shard.num_heads, shard.num_kv_heads, MODEL["D"], MODEL["layers"]
+    experiment = bool(args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1)
     if args.heads:
         Hq, Hkv, D = (int(x) for x in args.heads.split(","))
     ps = PAGE_SIZE
-    lens0 = cfg2_lengths(args.copies or tp)          # global batch 64 * tp
+    lens0 = W.cfg2_lengths(args.copies or tp)          # global batch 64 * tp
     if args.fixed_len:
         lens0 = [args.fixed_len] * (args.batch or 1)
     if args.len_scale > 1:
@@ -118,43 +115,9 @@ def main():
     if args.layers:
         L = args.layers
     B = len(lens0)
-    total_steps = args.warmup + args.steps + 8
-    pages_needed = sum(-(-(l + total_steps) // ps) for l in lens0) + 8
-    ctx = max(2048 * args.len_scale, args.fixed_len) + 64 + total_steps
-
-    kv = m.KVCache(size=pages_needed * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16,
-                   layer_num=L, device=dev, device_free_list=os.environ.get("M355_DEVICE_FREE_LIST", "1") != "0")
-    pm = m.PageManager(page_size=ps, max_req_num=B, max_context_len=ctx // ps * ps + ps, device=dev)
-    g = torch.Generator().manual_seed(0)
-    kv.set_free_pages(torch.randperm(pages_needed, generator=g).tolist())     # shuffled physical pages
-    gg = torch.Generator(device=dev).manual_seed(1234 + rank)
-    for l in range(L):                                                           # random KV content, resident in HBM
-        kv._store[l].copy_(torch.randn(kv._store[l].shape, generator=gg, device=dev, dtype=torch.float32))
-    backend = m.MI355AttnBackend(SimpleNamespace(device=dev, page_size=ps, kvcache=kv, page_manager=pm))
-    layers = [m.Attention(i, Hq, Hkv, D) for i in range(L)]
-
-    reqs = [m.Req(i, list(range(l))) for i, l in enumerate(lens0)]
-    for r in reqs:
-        r.fill_ids = r.origin_input_ids
-    batch = m.Batch(reqs, pm, kv, device=dev)
-    batch.prepare_for_prefill()                      # page tables for the cached context (KV content is synthetic)
-    batch.attn_backend = backend
-    qkv = torch.randn((B, (Hq + 2 * Hkv) * D), generator=gg, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
-    next_ids = torch.zeros(B, dtype=torch.int64, device=dev)
-    red = torch.zeros((B, hidden), dtype=torch.bfloat16, device=dev)
-
-    if args.chunk >= 0:
-        import mi355_attn.backend as be
-        be.pick_decode_chunk = lambda total, hkv: args.chunk
-
-    def step():
-        batch.output_ids = next_ids
-        batch.prepare_for_decode()
-        backend.init_forward_metadata(batch)
-        for layer in layers:
-            o = layer(q, k, v, batch)
-        return o
+    case = W.decode_case(dev, Hq, Hkv, D, lens0, L, ps=ps, room=args.warmup + args.steps + 16, seed=1234 + rank,
+                         device_free_list=os.environ.get("M355_DEVICE_FREE_LIST", "1") != "0")
+    batch, backend = case.batch, case.backend
 
     def fence():
         if tp > 1:
@@ -162,12 +125,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        W.decode_step(case)
     fence()
     lens_start = list(batch.seq_lens_host)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        W.decode_step(case)
     fence()
     dt = time.perf_counter() - t0
     if tp > 1:
@@ -175,181 +138,269 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
-    # bytes of step i: lengths are lens_start + i + 1
-    step_bytes = 0
+    step_bytes = 0                                     # bytes of step i: lengths are lens_start + i + 1
     for i in range(args.steps):
         cur = [l + i + 1 for l in lens_start]
-        step_bytes += L * (attn_bytes_per_layer(cur, Hq, Hkv, D, ps) + kv_store_bytes_per_layer(B, Hkv, D))
-    value = step_bytes * tp / dt / 1e9               # every rank moves the same number of bytes
+        step_bytes += L * (W.attn_bytes_per_layer(cur, Hq, Hkv, D, ps) + W.kv_store_bytes_per_layer(B, Hkv, D))
+    value = step_bytes * tp / dt / 1e9                 # every rank moves the same number of bytes
 
     # ---- roofline of the dominant kernel: the steps' decode launches only, all layers back to back
     lens_now = list(batch.seq_lens_host)
-    md = backend.forward_metadata
-    reps = 20
-    ws = backend._ws(ops.decode_workspace_bytes(B, Hq, D, md.max_seq_len, md.chunk_tokens), dev)
-    pools = [kv.get_kv_cache(l) for l in range(L)]
-    out = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=dev)
-
-    planned = backend.decode_mode == "planned"
-    fused = planned and backend.fused_store and os.environ.get("M355_BENCH_ROOFLINE_FUSED", "1") != "0"   # the launch the steps make
-    if planned:
-        ws = backend._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), dev)
-
-    def attn_only():
-        for kp, vp in pools:
-            if planned:
-                ops.decode_attn_planned(q, kp, vp, md.plan, Hq, workspace=ws, out=out, k_new=k if fused else None,
-                                        v_new=v if fused else None)
-            else:
-                ops.decode_attn(q, kp, vp, pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, md.max_seq_len,
-                                chunk_tokens=md.chunk_tokens, workspace=ws, out=out)
-
-    attn_only()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        attn_only()
-    e1.record()
-    torch.cuda.synchronize()
-    us_per_launch = e0.elapsed_time(e1) * 1e3 / (reps * L)
-    bytes_launch = attn_bytes_per_layer(lens_now, Hq, Hkv, D, ps) + (kv_store_bytes_per_layer(B, Hkv, D) if fused else 0)
-    achieved = bytes_launch / (us_per_launch * 1e-6) / 1e9
-
-    traffic = pmc_traffic(planned) if tp == 1 and not (args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1) else None
-
-    # ---- the layer's one collective, outside the path: o_proj's row-parallel all-reduce, timed on its own
-    def time_allreduce(t, reps):
-        for _ in range(3):
-            all_reduce_rows(t)
-        fence()
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record()
-        for _ in range(reps):
-            all_reduce_rows(t)
-        a1.record()
-        torch.cuda.synchronize()
-        us = torch.tensor([a0.elapsed_time(a1) * 1e3 / reps], device=dev, dtype=torch.float64)
-        dist.all_reduce(us, op=dist.ReduceOp.MAX)
-        nbytes = t.numel() * t.element_size()
-        return {"tensor": f"{list(t.shape)} bf16", "bytes": nbytes, "us": round(float(us.item()), 2),
-                "algbw_GBps": round(nbytes / float(us.item()) / 1e3, 1),
-                "busbw_GBps": round(nbytes / float(us.item()) / 1e3 * 2 * (tp - 1) / tp, 1)}
-
-    allreduce = allreduce_cfg4 = None
-    if tp > 1:
-        allreduce = time_allreduce(red, 3 if rehearse else 50)          # (gloo: ~1 s per bf16 all-reduce)
-        # SURVEY 8d cfg4 (Llama-3-8B, hidden 4096): the decode-size and the prefill-size message of that model
-        if not rehearse:                               # (gloo reduces 40 MB of bf16 on the host: minutes, and meaningless)
-            allreduce_cfg4 = {
-                "decode_B64": time_allreduce(torch.zeros((64, 4096), dtype=torch.bfloat16, device=dev), 50),
-                "prefill_T4863": time_allreduce(torch.zeros((4863, 4096), dtype=torch.bfloat16, device=dev), 10)}
-
-    # ---- f3, first measurement: o_proj (row-parallel GEMM) + its all-reduce, back to back against pipelined over
-    # row blocks (mi355_attn.tp.row_parallel_linear).  Llama-3-8B shape: hidden 4096, this rank's Hq*D input columns.
-    def time_o_proj(T, chunks, reps):
-        if rehearse and rank == 0:
-            print(f"[rehearsal] o_proj T={T} chunks={chunks}", file=sys.stderr, flush=True)
-        k_in = 4096 // tp
-        x = torch.randn((T, k_in), device=dev, dtype=torch.bfloat16)
-        w = torch.randn((4096, k_in), device=dev, dtype=torch.bfloat16) * 0.02
-        for _ in range(3):
-            row_parallel_linear(x, w, chunks)
-        fence()
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record()
-        for _ in range(reps):
-            row_parallel_linear(x, w, chunks)
-        a1.record()
-        torch.cuda.synchronize()
-        us = torch.tensor([a0.elapsed_time(a1) * 1e3 / reps], device=dev, dtype=torch.float64)
-        dist.all_reduce(us, op=dist.ReduceOp.MAX)
-        return round(float(us.item()), 2)
-
-    o_proj = None
-    if tp > 1 and (not rehearse or os.environ.get("M355_BENCH_REHEARSE_OPROJ") == "1"):
-        try:
-            o_proj = {"shape": f"x [T, {4096 // tp}] @ w [4096, {4096 // tp}]^T bf16, SUM over {tp} ranks", "us": {
-                f"T{T}": {f"chunks{c}": time_o_proj(T, c, reps)
-                          for c in cs} for T, cs, reps in (((64, (1, 2), 2), (256, (1, 4), 2)) if rehearse else
-                                                           ((64, (1, 2), 50), (4863, (1, 2, 4, 8), 10)))}}
-        except Exception as e:      # noqa: BLE001 - a side measurement must not take the bench line down
-            o_proj = {"error": repr(e)[:200]}
+    us_per_launch, bytes_launch = W.time_decode_launches(case, reps=20)
+    achieved = bytes_launch / us_per_launch / 1e3
+    kernel = W.decode_kernel_name(case)
+    traffic, traffic_source = (None, None) if (tp > 1 or experiment) else pmc_traffic(kernel)
 
     cpu = None
     if rank == 0 and tp == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(kv, pm, batch, q, lens_now, Hq, Hkv, D, ps)
+        cpu = cpu_baseline(case, lens_now)
 
+    line = {
+        "metric": "decode_attn_hbm_throughput", "value": round(value, 1), "unit": "GB/s", "n_gpus": tp,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "Llama-3.2-1B decode attention path (kv_store + paged decode attn, 16 layers), "
+                               f"batch {B} ragged 64..2048 (+ctx), page_size 16, shuffled pages",
+                   "global_batch": B, "sum_seq_len": sum(lens_now), "page_size": ps, "layers": L,
+                   "heads_per_gpu": [Hq, Hkv, D], "parallelism": f"tp{tp}", "decode_mode": backend.decode_mode},
+        "pct_of_hbm_peak_whole_step": round(100 * value / tp / W.HBM_PEAK_GBPS, 2),
+        "roofline": {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": W.HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / W.HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_source, "us_per_launch": round(us_per_launch, 3),
+                     "algorithmic_bytes_per_launch": bytes_launch, "launch": "attention + fused KV store"},
+        "cpu_baseline": cpu,
+    }
+    del case, batch, backend
+    torch.cuda.empty_cache()
+
+    if not args.no_extras and not experiment:
+        line["extras"] = extras(dev, tp, rank, rehearse, fence)
     if rank == 0:
-        line = {
-            "metric": "decode_attn_hbm_throughput", "value": round(value, 1), "unit": "GB/s", "n_gpus": tp,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Llama-3.2-1B decode attention path (kv_store + paged decode attn, 16 layers), "
-                                   f"batch {B} ragged 64..2048 (+ctx), page_size 16, shuffled pages",
-                       "global_batch": B, "sum_seq_len": sum(lens_now), "page_size": ps, "layers": L,
-                       "heads_per_gpu": [Hq, Hkv, D], "parallelism": f"tp{tp}", "decode_mode": backend.decode_mode,
-                       "decode_chunk_tokens": md.chunk_tokens},
-            "pct_of_hbm_peak_whole_step": round(100 * value / tp / HBM_PEAK_GBPS, 2),
-            "roofline": {"kernel": ("m355::decode_stream_kernel" if os.environ.get("M355_STREAM_KERNEL", "mfma")[:1] == "v"
-                                     else "m355::decode_mfma_kernel") + " (+ stream_merge_kernel)" if planned
-                         else "m355::decode_split_kernel (+ decode_merge_kernel)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "us_per_launch": round(us_per_launch, 3), "algorithmic_bytes_per_launch": bytes_launch,
-                         "launch": "attention + fused KV store" if fused else "attention only"},
-            "cpu_baseline": cpu,
-        }
-        if allreduce is not None:
-            line["allreduce_o_proj"] = allreduce
-            line["allreduce_o_proj_llama3_8b"] = allreduce_cfg4
-            line["o_proj_all_reduce"] = o_proj
         print(json.dumps(line), flush=True)
     if tp > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic(planned: bool):
-    """HBM bytes per attention launch (main + merge kernel) from the newest committed PMC summary of this same
-    command (profiles/rNN_pmc_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE and
-    WRITE_SIZE passes, already corrected per MI355X_MICROARCH.md).  None when no summary covers the kernels."""
-    import glob
+# ------------------------------------------------------------------------------------------------
+# side measurements: the rest of BASELINE.json's metric and configs, in the same driver-run record
+# ------------------------------------------------------------------------------------------------
+def guarded(fn, *a, **k):
+    """A side measurement must not take the bench line down: its failure is reported in its own field.  Under TP every
+    rank takes the same path through this (an exception on one rank only would leave the others in a collective)."""
+    try:
+        return fn(*a, **k)
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        torch.cuda.empty_cache()
+
+
+def extras(dev, tp, rank, rehearse, fence) -> dict:
+    from harness import workloads as W
+    out = {}
+    if tp == 1:
+        # the 8B head shape on the same batch as the headline (SURVEY §8 table: (32, 8, 128))
+        out["decode_8b_shape"] = guarded(W.decode_shape_report, dev, 32, 8, 128, W.cfg2_lengths(1), 16)
+    if tp in (1, 8):
+        # cfg5: what ONE rank of Llama-3-70B at TP=8 streams - (8, 1, 128), every request 32 768 tokens (16 of the 80 layers)
+        out["decode_cfg5_per_rank"] = {
+            f"B{b}": guarded(W.decode_shape_report, dev, 8, 1, 128, [32768] * b, 16, reps=10) for b in (1, 8, 32)}
+        out["decode_cfg5_per_rank"]["note"] = ("per-rank shape of Llama-3-70B at TP=8, context 32 768, page_size 16, "
+                                               + ("one rank of 8 measured" if tp == 8 else "measured on one GPU"))
+    # cfg3 / cfg4: Llama-3-8B prefill over shared cached prefixes, this rank's heads
+    out["prefill_cfg3" if tp == 1 else "prefill_cfg3_per_rank"] = guarded(prefill_cfg3, dev, tp)
+    out["bench_one_batch_llama3_8b"] = guarded(one_batch, dev, tp, rank, rehearse)
+    if tp > 1:
+        out.update(guarded(collective_legs, dev, tp, rank, rehearse, fence))
+    if tp == 1 and rank == 0:
+        out["cpu_baseline_cfg1"] = guarded(cpu_baseline_cfg1)
+    return out
+
+
+def prefill_cfg3(dev, tp):
+    from harness import workloads as W
+    c = W.prefill_cfg3_case(dev, Hq=32 // tp, Hkv=8 // tp, D=128, layers=8)
+    r = W.time_prefill(c, reps=10)
+    r["workload"] = "Llama-3-8B shape, 4 groups x 4 requests, 1024-token shared cached prefix + 128..512 new tokens"
+    return r
+
+
+def one_batch(dev, tp, rank, rehearse):
+    """bench_one_batch's latency mode (reference bench_one_batch.py:72-84, 195-214) on Llama-3-8B with synthetic weights:
+    B=64, input 1024, 32 output tokens; tok/s = B * decode steps / sum(decode step time).  TP=N under torch.distributed."""
+    import bench_one_batch as ob
+    from harness.llama_shell import SHAPES, HarnessRunner
+    model = "tiny" if rehearse else "llama-3-8b"          # (a gloo rehearsal cannot all-reduce 8B-size activations in minutes)
+    bs, il, ol = (4, 64, 8) if rehearse else (64, 1024, 32)
+    shape = SHAPES[model]
+    runner = HarnessRunner(shape, PAGE_SIZE, max_total_tokens=bs * (il + ol + 2 * PAGE_SIZE) + 64 * PAGE_SIZE, max_reqs=bs,
+                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=tp, device=dev)
+    quiet = lambda *a, **k: None      # noqa: E731
+    res = {"model": shape.name, "weights": "synthetic", "dtype": "bf16", "tp_size": tp, "batch_size": bs, "input_len": il,
+           "output_len": ol, "page_size": PAGE_SIZE}
+    for mode in (("eager", False), ("graph", True)) if tp == 1 else (("eager", False),):
+        r = ob.latency_test(runner, ob.BenchArgs(graph=mode[1], model=model), bs, il, ol, quiet, tp)
+        res[mode[0]] = {"prefill_tok_per_s": round(r["prefill_throughput"], 1), "prefill_latency_ms": round(r["prefill_latency"] * 1e3, 2),
+                        "decode_tok_per_s": round(r["decode_throughput"], 1),
+                        "median_decode_step_ms": round(r["median_decode_latency"] * 1e3, 3)}
+    return res
+
+
+def collective_legs(dev, tp, rank, rehearse, fence):
+    """The layer's one exchange step, outside the path (layers/linear.py:228-232): RCCL all-reduce of the o_proj output at
+    the decode and prefill sizes of Llama-3-8B, and o_proj GEMM + all-reduce back to back against the
+    f3 variants (mi355_attn.tp)."""
+    from mi355_attn.tp import all_reduce_rows, row_parallel_linear
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        fence()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(reps):
+            fn()
+        a1.record()
+        torch.cuda.synchronize()
+        us = torch.tensor([a0.elapsed_time(a1) * 1e3 / reps], device=dev, dtype=torch.float64)
+        dist.all_reduce(us, op=dist.ReduceOp.MAX)
+        return float(us.item())
+
+    def allreduce(T, hidden, reps):
+        t = torch.zeros((T, hidden), dtype=torch.bfloat16, device=dev)
+        us = timed(lambda: all_reduce_rows(t), reps)
+        nbytes = t.numel() * 2
+        return {"tensor": f"[{T}, {hidden}] bf16", "bytes": nbytes, "us": round(us, 2), "algbw_GBps": round(nbytes / us / 1e3, 1),
+                "busbw_GBps": round(nbytes / us / 1e3 * 2 * (tp - 1) / tp, 1)}
+
+    def o_proj(T, chunks, reps):
+        k_in = 4096 // tp
+        x = torch.randn((T, k_in), device=dev, dtype=torch.bfloat16)
+        w = torch.randn((4096, k_in), device=dev, dtype=torch.bfloat16) * 0.02
+        return round(timed(lambda: row_parallel_linear(x, w, chunks), reps), 2)
+
+    if rehearse:
+        return {"allreduce_o_proj_llama3_8b": {"decode_B64": allreduce(64, 256, 2)},
+                "o_proj_all_reduce": {"us": {"T64": {"chunks1": o_proj(64, 1, 2), "chunks2": o_proj(64, 2, 2)}}}}
+    return {
+        "allreduce_o_proj_llama3_8b": {"decode_B64": allreduce(64, 4096, 50), "prefill_T4863": allreduce(4863, 4096, 10),
+                                       "link_peak_GBps": "7 xGMI links x ~153 GB/s per GPU"},
+        "o_proj_all_reduce": {"shape": f"x [T, {4096 // tp}] @ w [4096, {4096 // tp}]^T bf16, SUM over {tp} ranks",
+                              "us": {"T64": {f"chunks{c}": o_proj(64, c, 50) for c in (1, 2)},
+                                     "T4863": {f"chunks{c}": o_proj(4863, c, 10) for c in (1, 2, 4, 8)}}}}
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per attention launch from the newest committed PMC summary of this same command
+    (profiles/rNN_pmc_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE and WRITE_SIZE
+    passes, corrected per MI355X_MICROARCH.md).  NOT measured in this run: the second value names the file."""
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        kernels = json.load(f)["kernels"]
-    main = "decode_stream_kernel" if os.environ.get("M355_STREAM_KERNEL", "mfma")[:1] == "v" else "decode_mfma_kernel"
-    want = (main, "stream_merge_kernel") if planned else ("decode_split_kernel", "decode_merge_kernel")
-    tot = 0
-    for w in want:
-        hit = [e["hbm_bytes_per_launch"] for k, e in kernels.items() if w in k]
-        if not hit:
-            return None
-        tot += hit[0]
-    return tot
+    want = [w.split("::")[-1].strip(" ()+") for w in kernel.split("(+") if w.strip()]
+    for path in reversed(files):
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        tot, ok = 0, True
+        for w in want:
+            hit = [e["hbm_bytes_per_launch"] for k, e in kernels.items() if w in k]
+            ok = ok and bool(hit)
+            tot += hit[0] if hit else 0
+        if ok:
+            return tot, "profiles/" + os.path.basename(path) + " (separate rocprofv3 --pmc passes of this command, not this run)"
+    return None, None
 
 
-def cpu_baseline(kv, pm, batch, q, lens, Hq, Hkv, D, ps):
-    """The oracle's decode attention (per-sequence gather + SDPA, reference torch_native_backend.py:121-193) on
-    the host cores: ONE layer of the same batch, 2 warm-ups + 5 timed runs (~10 s)."""
+def cpu_baseline(case, lens):
+    """The oracle's decode attention (per-sequence gather + SDPA, reference torch_native_backend.py:121-193) on the
+    host cores: ONE layer of the same batch, 3 warm-ups + median of 10."""
+    from harness import workloads as W
     from oracle import attention_ref as A
     n_thr = torch.get_num_threads()
-    kp, vp = (t.cpu() for t in kv.get_kv_cache(0))
-    table = pm.page_table.cpu()
-    rows, sl = batch.page_table_ids.cpu(), batch.seq_lens.cpu()
-    qc = q.cpu().reshape(len(lens), Hq, D)
-    for _ in range(2):
-        A.decode_attn_ref(qc, kp, vp, table, rows, sl, ps)
+    kp, vp = (t.cpu().contiguous() for t in case.kv.get_kv_cache(0))
+    table = case.pm.page_table.cpu()
+    rows, sl = case.batch.page_table_ids.cpu(), case.batch.seq_lens.cpu()
+    qc = case.q.cpu().reshape(len(lens), case.Hq, case.D)
+    for _ in range(3):
+        A.decode_attn_ref(qc, kp, vp, table, rows, sl, case.ps)
     ts = []
-    for _ in range(5):
+    for _ in range(10):
         t0 = time.perf_counter()
-        A.decode_attn_ref(qc, kp, vp, table, rows, sl, ps)
+        A.decode_attn_ref(qc, kp, vp, table, rows, sl, case.ps)
         ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return {"value": round(attn_bytes_per_layer(lens, Hq, Hkv, D, ps) / med / 1e9, 3), "unit": "GB/s", "cores": n_thr,
-            "kind": "port", "sample": f"decode attention of 1 of 16 layers, same batch, bf16, median of 5 ({med * 1e3:.1f} ms/layer)"}
+    med = statistics.median(ts)
+    return {"value": round(W.attn_bytes_per_layer(lens, case.Hq, case.Hkv, case.D, case.ps) / med / 1e9, 3), "unit": "GB/s",
+            "cores": n_thr, "kind": "port",
+            "sample": f"decode attention of 1 of 16 layers, same batch, bf16, 3 warm-ups + median of 10 ({med * 1e3:.1f} ms/layer)"}
+
+
+def cpu_baseline_cfg1():
+    """BASELINE.json configs[0] on the host cores, through the oracle (the reference's CPU-runnable case): Llama-3.2-1B
+    head shape, page_size 1, batch 1, 128-token prompt (`arange(128)`), then 16 decode steps; metadata + attention per
+    layer, 3 warm-ups + median of 10.  Weights play no part in the path, so tok/s here is the attention
+    path alone over the model's 16 layers."""
+    import numpy as np
+    from oracle import attention_ref as A
+    from oracle import memory_ref as M
+    Hq, Hkv, D, L, ps, P, steps = 32, 8, 64, 16, 1, 128, 16
+    g = torch.Generator().manual_seed(0)
+    S = 512
+    kp = torch.randn((S, Hkv, D), generator=g).to(torch.bfloat16)
+    vp = torch.randn((S, Hkv, D), generator=g).to(torch.bfloat16)
+    qkv = torch.randn((P + steps, (Hq + 2 * Hkv) * D), generator=g).to(torch.bfloat16)
+
+    def med(fn, warm=3, n=10):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    def fresh():
+        return M.RefPagePool(S, ps), M.RefPageTable(ps, 8, 131076)
+
+    def prefill_meta():
+        pool, pt = fresh()
+        return M.prepare_for_prefill_ref([M.RefReq(list(range(P)))], pool, pt), pool, pt
+
+    t_prep_prefill = med(lambda: prefill_meta())
+    meta, pool, pt = prefill_meta()
+    table = torch.from_numpy(pt.table)
+    rows, sl, pl = (torch.from_numpy(np.asarray(x)) for x in (meta.page_table_ids, meta.seq_lens, meta.prefix_lens))
+    q, k, v = (t.reshape(P + steps, -1, D) for t in qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
+    loc = torch.from_numpy(meta.out_cache_loc)
+
+    def extend_layer():
+        A.write_kv_ref(kp, vp, loc, k[:P], v[:P])
+        return A.extend_attn_ref(q[:P], kp, vp, table, rows, sl, pl, ps)
+
+    t_extend = med(extend_layer)
+    t_prep_decode, t_decode = [], []
+    for s in range(steps):
+        t0 = time.perf_counter()
+        meta = M.prepare_for_decode_ref(meta, [0], pool, pt)
+        t_prep_decode.append(time.perf_counter() - t0)
+        table = torch.from_numpy(pt.table)
+        sl = torch.from_numpy(np.asarray(meta.seq_lens))
+        dloc = torch.from_numpy(meta.out_cache_loc)
+
+        def decode_layer():
+            A.write_kv_ref(kp, vp, dloc, k[P + s:P + s + 1], v[P + s:P + s + 1])
+            return A.decode_attn_ref(q[P + s:P + s + 1], kp, vp, table, rows, sl, ps)
+
+        t_decode.append(med(decode_layer, warm=1, n=5) if s else med(decode_layer))
+    dec_layer = statistics.median(t_decode)
+    step_s = statistics.median(t_prep_decode) + L * dec_layer
+    return {"workload": "Llama-3.2-1B head shape, CPU, page_size 1, batch 1, 128-token prompt + 16 decode steps (oracle)",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "prepare_for_prefill_ms": round(t_prep_prefill * 1e3, 3), "extend_attn_ms_per_layer": round(t_extend * 1e3, 3),
+            "prepare_for_decode_ms": round(statistics.median(t_prep_decode) * 1e3, 3),
+            "decode_attn_ms_per_layer": round(dec_layer * 1e3, 4),
+            "decode_attn_path_tok_per_s": round(1.0 / step_s, 1),
+            "decode_kv_GBps": round(4 * Hkv * D * (P + steps // 2) / dec_layer / 1e9, 3),
+            "protocol": "3 warm-ups + median of 10 (decode: median over the 16 steps of per-step medians)"}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,183 @@
+"""Synthetic workloads of BASELINE.json's configs, shared by bench.py and the tools.
+
+Everything here is device set-up plus HIP-event timing around calls into mi355_attn; nothing computes on the host.
+"""
+from __future__ import annotations
+
+import random
+from types import SimpleNamespace
+from typing import List, Optional, Sequence
+
+import torch
+
+import mi355_attn as m
+from mi355_attn import ops
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: bf16 dense
+
+
+def cfg2_lengths(n_copies: int = 1) -> List[int]:
+    """`random.seed(0); [randint(64, 2048) for _ in range(64)]`; further copies use seeds 1, 2, ..."""
+    lens: List[int] = []
+    for c in range(n_copies):
+        random.seed(c)
+        lens += [random.randint(64, 2048) for _ in range(64)]
+    return lens
+
+
+def attn_bytes_per_layer(lens: Sequence[int], Hq: int, Hkv: int, D: int, ps: int) -> int:
+    """bytes_all = 4*Hkv*D*sum(L) + 4*B*Hq*D + 4*sum(ceil(L/ps)) + 16*B."""
+    B = len(lens)
+    return 4 * Hkv * D * sum(lens) + 4 * B * Hq * D + 4 * sum(-(-l // ps) for l in lens) + 16 * B
+
+
+def kv_store_bytes_per_layer(T: int, Hkv: int, D: int) -> int:
+    return 8 * T * Hkv * D + 8 * T
+
+
+def decode_case(dev: str, Hq: int, Hkv: int, D: int, lens: Sequence[int], layers: int, ps: int = 16, room: int = 64,
+                seed: int = 1234, device_free_list: bool = True) -> SimpleNamespace:
+    """A batch with `lens` cached tokens per request in `layers` distinct, randomly filled KV pools, physical pages
+    handed out in shuffled order, ready for prepare_for_decode (`room` further tokens per request fit)."""
+    B = len(lens)
+    pages = sum(-(-(l + room) // ps) for l in lens) + 8
+    kv = m.KVCache(size=pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=layers,
+                   device=dev, device_free_list=device_free_list)
+    pm = m.PageManager(page_size=ps, max_req_num=B, max_context_len=(max(lens) + room) // ps * ps + 2 * ps, device=dev)
+    kv.set_free_pages(torch.randperm(pages, generator=torch.Generator().manual_seed(0)).tolist())
+    gg = torch.Generator(device=dev).manual_seed(seed)
+    for l in range(layers):                                      # random KV content, resident in HBM
+        kv._store[l].copy_(torch.randn(kv._store[l].shape, generator=gg, device=dev, dtype=torch.float32))
+    backend = m.MI355AttnBackend(SimpleNamespace(device=dev, page_size=ps, kvcache=kv, page_manager=pm))
+    attn = [m.Attention(i, Hq, Hkv, D) for i in range(layers)]
+    reqs = [m.Req(i, list(range(l))) for i, l in enumerate(lens)]
+    for r in reqs:
+        r.fill_ids = r.origin_input_ids
+    batch = m.Batch(reqs, pm, kv, device=dev)
+    batch.prepare_for_prefill()                                  # page tables of the cached context (KV content is synthetic)
+    batch.attn_backend = backend
+    qkv = torch.randn((B, (Hq + 2 * Hkv) * D), generator=gg, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)      # strided views of one projection, as models/llama.py:133-134
+    return SimpleNamespace(dev=dev, Hq=Hq, Hkv=Hkv, D=D, ps=ps, L=layers, B=B, kv=kv, pm=pm, backend=backend, attn=attn,
+                           batch=batch, q=q, k=k, v=v, next_ids=torch.zeros(B, dtype=torch.int64, device=dev))
+
+
+def decode_step(c: SimpleNamespace):
+    """One decode step of the hot path: metadata (host plan + one kernel), then every layer's KV store + attention."""
+    c.batch.output_ids = c.next_ids
+    c.batch.prepare_for_decode()
+    c.backend.init_forward_metadata(c.batch)
+    o = None
+    for layer in c.attn:
+        o = layer(c.q, c.k, c.v, c.batch)
+    return o
+
+
+def decode_kernel_name(c: SimpleNamespace) -> str:
+    """Which attention kernel the library runs for this batch (it decides from B and the head shape alone): the
+    single-launch share kernel needs no partials workspace, the per-wave-range kernel + merge does."""
+    cap = sum(c.batch.seq_lens_host)
+    if ops.decode_planned_workspace_bytes(c.B, c.Hq, c.Hkv, c.D, cap) == 0:
+        return "m355::decode_share_kernel"
+    return "m355::decode_mfma_kernel (+ m355::stream_merge_kernel)"
+
+
+def time_decode_launches(c: SimpleNamespace, reps: int = 20, fused: bool = True):
+    """The attention launches of the CURRENT step alone, exactly as decode_step makes them (fused KV store included),
+    all layers back to back on torch's current stream, HIP events around `reps` passes.
+    Returns (us per launch, algorithmic bytes per launch)."""
+    md = c.backend.forward_metadata
+    assert md is not None and md.decode and md.plan is not None, "run decode_step first"
+    lens = list(c.batch.seq_lens_host)
+    ws = c.backend._ws(ops.decode_planned_workspace_bytes(c.B, c.Hq, c.Hkv, c.D, md.plan.capacity), c.dev)
+    if ws is None:
+        ws = torch.empty(16, dtype=torch.uint8, device=c.dev)
+    pools = [c.kv.get_kv_cache(l) for l in range(c.L)]
+    out = torch.empty((c.B, c.Hq * c.D), dtype=torch.bfloat16, device=c.dev)
+
+    def launches():
+        for kp, vp in pools:
+            ops.decode_attn_planned(c.q, kp, vp, md.plan, c.Hq, workspace=ws, out=out, k_new=c.k if fused else None,
+                                    v_new=c.v if fused else None)
+
+    launches()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launches()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * c.L)
+    nbytes = attn_bytes_per_layer(lens, c.Hq, c.Hkv, c.D, c.ps) + (kv_store_bytes_per_layer(c.B, c.Hkv, c.D) if fused else 0)
+    return us, nbytes
+
+
+def decode_shape_report(dev: str, Hq: int, Hkv: int, D: int, lens: Sequence[int], layers: int, reps: int = 20,
+                        ps: int = 16) -> dict:
+    """Launch-level roofline of decode attention for one head shape / batch (a side measurement of bench.py)."""
+    c = decode_case(dev, Hq, Hkv, D, lens, layers, ps=ps, room=8)
+    for _ in range(2):
+        decode_step(c)
+    us, nbytes = time_decode_launches(c, reps)
+    gbps = nbytes / us / 1e3
+    B = len(lens)
+    return {"heads_per_gpu": [Hq, Hkv, D], "batch": B, "sum_seq_len": sum(c.batch.seq_lens_host), "layers": layers,
+            "page_size": ps, "kernel": decode_kernel_name(c), "us_per_launch": round(us, 2),
+            "algorithmic_bytes_per_launch": nbytes, "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+            "attn_tok_per_s_per_layer": round(B / us * 1e6, 0)}
+
+
+def prefill_cfg3_case(dev: str, Hq: int = 32, Hkv: int = 8, D: int = 128, ps: int = 16, prefix: int = 1024, groups: int = 4,
+                      per_group: int = 4, suffix=(128, 512), layers: int = 8) -> SimpleNamespace:
+    """`groups` x `per_group` requests, every group shares one cached prefix (the SAME physical pages,
+    as RadixCache hits give them), unique suffixes `random.seed(0); randint(*suffix)`; shuffled physical pages."""
+    random.seed(0)
+    B = groups * per_group
+    ext = [random.randint(*suffix) for _ in range(B)]
+    pre = [prefix // ps * ps] * B
+    seq = [p + e for p, e in zip(pre, ext)]
+    T = sum(ext)
+    npp = pre[0] // ps
+    pages_total = groups * npp + sum(-(-s // ps) - npp for s in seq) + 4
+    it = iter(torch.randperm(pages_total, generator=torch.Generator().manual_seed(0)).tolist())
+    W = max(-(-s // ps) for s in seq) + 1
+    table = torch.zeros((B, W), dtype=torch.int32)
+    for gi in range(groups):
+        shared = [next(it) for _ in range(npp)]
+        for k in range(per_group):
+            b = gi * per_group + k
+            own = [next(it) for _ in range(-(-seq[b] // ps) - npp)]
+            table[b, : npp + len(own)] = torch.tensor(shared + own, dtype=torch.int32)
+    g = torch.Generator(device=dev).manual_seed(0)
+    pools = [(torch.randn((pages_total * ps, Hkv, D), generator=g, device=dev).to(torch.bfloat16),
+              torch.randn((pages_total * ps, Hkv, D), generator=g, device=dev).to(torch.bfloat16)) for _ in range(layers)]
+    q = torch.randn((T, Hq * D), generator=g, device=dev).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(torch.tensor(ext).cumsum(0)), dtype=torch.int32, device=dev)
+    return SimpleNamespace(dev=dev, Hq=Hq, Hkv=Hkv, D=D, ps=ps, B=B, T=T, ext=ext, pre=pre, seq=seq, pools=pools, q=q, cu=cu,
+                           table=table.to(dev), rows=torch.arange(B, device=dev), dseq=torch.tensor(seq, device=dev),
+                           dpre=torch.tensor(pre, device=dev), out=torch.empty((T, Hq * D), dtype=torch.bfloat16, device=dev))
+
+
+def time_prefill(c: SimpleNamespace, reps: int = 10) -> dict:
+    """Extend attention over every pool of the case back to back, HIP events; FLOPs = 4*Hq*D*sum(E*P + E*(E+1)/2)."""
+    def run():
+        for kp, vp in c.pools:
+            ops.prefill_attn(c.q, kp, vp, c.table, c.rows, c.dseq, c.dpre, c.cu, c.ps, c.Hq, max(c.ext), max(c.seq), out=c.out)
+
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * len(c.pools))
+    flops = 4 * c.Hq * c.D * sum(e * p + e * (e + 1) // 2 for e, p in zip(c.ext, c.pre))
+    byts = 4 * c.Hkv * c.D * sum(c.seq) + 4 * c.T * c.Hq * c.D
+    return {"heads_per_gpu": [c.Hq, c.Hkv, c.D], "batch": c.B, "prefix": c.pre[0], "new_tokens": c.T, "page_size": c.ps,
+            "kernel": "m355::prefill_wg_kernel", "us_per_layer": round(us, 2), "gflop_per_layer": round(flops / 1e9, 2),
+            "tflops": round(flops / us / 1e6, 1), "frac_of_mfma_peak": round(flops / us / 1e6 / MFMA_PEAK_TFLOPS, 4),
+            "prefill_tok_per_s_per_layer": round(c.T / us * 1e6, 0), "min_bytes_MB": round(byts / 1e6, 2)}

@@ -14,7 +14,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "mini-sglang_amd"))
-from mi355_attn import ops  # noqa: E402
+from harness import workloads as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--heads", default="32,8,128")
@@ -29,54 +29,11 @@ args = ap.parse_args()
 
 dev = "cuda:0"
 Hq, Hkv, D = (int(x) for x in args.heads.split(","))
-ps = args.ps
 lo, hi = (int(x) for x in args.suffix.split(","))
-random.seed(0)
-B = args.groups * args.per_group
-ext = [random.randint(lo, hi) for _ in range(B)]
-pre = [args.prefix // ps * ps] * B
-seq = [p + e for p, e in zip(pre, ext)]
-T = sum(ext)
-# shared prefix pages per group, own pages for the suffix
-npp = pre[0] // ps
-pages_total = args.groups * npp + sum(-(-s // ps) - npp for s in seq) + 4
-perm = torch.randperm(pages_total, generator=torch.Generator().manual_seed(0)).tolist()
-it = iter(perm)
-W = max(-(-s // ps) for s in seq) + 1
-table = torch.zeros((B, W), dtype=torch.int32)
-for gi in range(args.groups):
-    shared = [next(it) for _ in range(npp)]
-    for k in range(args.per_group):
-        b = gi * args.per_group + k
-        own = [next(it) for _ in range(-(-seq[b] // ps) - npp)]
-        table[b, : npp + len(own)] = torch.tensor(shared + own, dtype=torch.int32)
-g = torch.Generator(device=dev).manual_seed(0)
-pools = [(torch.randn((pages_total * ps, Hkv, D), generator=g, device=dev).to(torch.bfloat16),
-          torch.randn((pages_total * ps, Hkv, D), generator=g, device=dev).to(torch.bfloat16)) for _ in range(args.layers)]
-q = torch.randn((T, Hq * D), generator=g, device=dev).to(torch.bfloat16)
-cu = torch.tensor([0] + list(torch.tensor(ext).cumsum(0)), dtype=torch.int32, device=dev)
-dt, dr = table.to(dev), torch.arange(B, device=dev)
-dseq, dpre = torch.tensor(seq, device=dev), torch.tensor(pre, device=dev)
-out = torch.empty((T, Hq * D), dtype=torch.bfloat16, device=dev)
-
-
-def run():
-    for kp, vp in pools:
-        ops.prefill_attn(q, kp, vp, dt, dr, dseq, dpre, cu, ps, Hq, max(ext), max(seq), out=out)
-
-
-run()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(args.reps):
-    run()
-e1.record()
-torch.cuda.synchronize()
-us = e0.elapsed_time(e1) * 1e3 / (args.reps * args.layers)
-flops = 4 * Hq * D * sum(e * p + e * (e + 1) // 2 for e, p in zip(ext, pre))
-byts = 4 * Hkv * D * sum(seq) + 4 * T * Hq * D
-print(json.dumps({"workload": f"prefill heads={Hq},{Hkv},{D} B={B} prefix={pre[0]} extend {lo}..{hi} (T={T}) ps={ps}",
-                  "us_per_layer": round(us, 2), "tflops": round(flops / us / 1e6, 1), "frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4),
-                  "gflop_per_layer": round(flops / 1e9, 2), "min_bytes_MB": round(byts / 1e6, 2),
+case = W.prefill_cfg3_case(dev, Hq, Hkv, D, ps=args.ps, prefix=args.prefix, groups=args.groups, per_group=args.per_group,
+                           suffix=(lo, hi), layers=args.layers)
+r = W.time_prefill(case, reps=args.reps)
+print(json.dumps({"workload": f"prefill heads={Hq},{Hkv},{D} B={case.B} prefix={case.pre[0]} extend {lo}..{hi} (T={case.T}) ps={args.ps}",
+                  "us_per_layer": r["us_per_layer"], "tflops": r["tflops"], "frac_of_2.5PF": r["frac_of_mfma_peak"],
+                  "gflop_per_layer": r["gflop_per_layer"], "min_bytes_MB": r["min_bytes_MB"],
                   "mode": os.environ.get("M355_PREFILL_MODE", "0")}))

@@ -33,7 +33,7 @@ rows = db.execute("select name, count(*), sum(duration), avg(duration), min(dura
 total = sum(r[2] for r in rows)
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (durations in ns)"])
+    w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras (durations in ns)"])
     w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"])
     for n, c, t, a, lo, hi in rows:
         w.writerow([short(n), c, int(t), round(a, 1), int(lo), int(hi), round(100 * t / total, 2)])
@@ -63,7 +63,7 @@ if os.path.exists(bj):
         txt = f.read().strip()
     if txt:
         bench = json.loads(txt.splitlines()[-1])
-out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --no-cpu-baseline "
+out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --no-cpu-baseline --no-extras "
                   "--steps 4 --warmup 2",
        "correction": "bytes = KiB*1024; reads doubled (gfx950 FETCH_SIZE counts 128-B requests as 64 B)",
        "kernels": traffic, "bench_line_same_box": bench}
