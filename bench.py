@@ -213,9 +213,44 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
     out["bench_one_batch_llama3_8b"] = guarded(one_batch, dev, tp, rank, rehearse)
     if tp > 1:
         out.update(guarded(collective_legs, dev, tp, rank, rehearse, fence))
+    if tp == 1:
+        out["o_proj_fused_single_gpu"] = guarded(o_proj_single_gpu, dev)
     if tp == 1 and rank == 0:
         out["cpu_baseline_cfg1"] = guarded(cpu_baseline_cfg1)
     return out
+
+
+def o_proj_single_gpu(dev):
+    """The GEMM + push + reduce launch of SURVEY §8 f3 with a world of one (no peer: its own slot only), against
+    F.linear, at the per-rank o_proj shapes of Llama-3-8B under TP 8 / 2 / 1, decode batch 64."""
+    from mi355_attn.tp import FusedRowParallel
+    res = {"what": "m355_oproj_allreduce, world 1, x [64, K] @ w [4096, K]^T bf16 vs torch matmul (hipBLASLt): GPU us per call, 20 calls replayed from a HIP graph"}
+    f = FusedRowParallel(4096, t_cap=256, local_world=1, device=dev)
+    try:
+        for K in (512, 2048, 4096):
+            x = torch.randn((64, K), device=dev, dtype=torch.bfloat16)
+            w = torch.randn((4096, K), device=dev, dtype=torch.bfloat16) * 0.02
+            t = {}
+            o = [torch.empty((64, 4096), device=dev, dtype=torch.bfloat16)]
+            for name, fn in (("fused", lambda: f([x], [w], out=o)), ("linear", lambda: torch.nn.functional.linear(x, w, out=o[0]) if False else torch.matmul(x, w.t(), out=o[0]))):
+                fn()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()                # 20 calls replayed from a graph: GPU time, not Python's launch rate
+                with torch.cuda.graph(g):
+                    for _ in range(20):
+                        fn()
+                g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                t[name] = round(e0.elapsed_time(e1) * 1e3 / 100, 2)
+            res[f"K{K}"] = t
+    finally:
+        f.close()
+    return res
 
 
 def prefill_cfg3(dev, tp):
@@ -235,15 +270,24 @@ def one_batch(dev, tp, rank, rehearse):
     bs, il, ol = (4, 64, 8) if rehearse else (64, 1024, 32)
     shape = SHAPES[model]
     runner = HarnessRunner(shape, PAGE_SIZE, max_total_tokens=bs * (il + ol + 2 * PAGE_SIZE) + 64 * PAGE_SIZE, max_reqs=bs,
-                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=tp, device=dev)
+                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=tp, device=dev, fused_row_parallel=tp > 1)
     quiet = lambda *a, **k: None      # noqa: E731
     res = {"model": shape.name, "weights": "synthetic", "dtype": "bf16", "tp_size": tp, "batch_size": bs, "input_len": il,
            "output_len": ol, "page_size": PAGE_SIZE}
-    for mode in (("eager", False), ("graph", True)) if tp == 1 else (("eager", False),):
-        r = ob.latency_test(runner, ob.BenchArgs(graph=mode[1], model=model), bs, il, ol, quiet, tp)
-        res[mode[0]] = {"prefill_tok_per_s": round(r["prefill_throughput"], 1), "prefill_latency_ms": round(r["prefill_latency"] * 1e3, 2),
-                        "decode_tok_per_s": round(r["decode_throughput"], 1),
-                        "median_decode_step_ms": round(r["median_decode_latency"] * 1e3, 3)}
+    fused = runner.model.fused
+    # TP=1: the eager loop and the captured-graph loop; TP=N: RCCL all-reduce after o_proj / down_proj, and the same run
+    # with the two as fused GEMM + one-shot reduce launches for the decode steps
+    for name, graph, use_fused in ((("eager", False, False), ("graph", True, False)) if tp == 1 else
+                                   (("eager_rccl", False, False), ("eager_fused_oproj", False, True))):
+        runner.model.fused = fused if use_fused else None
+        r = ob.latency_test(runner, ob.BenchArgs(graph=graph, model=model), bs, il, ol, quiet, tp)
+        res[name] = {"prefill_tok_per_s": round(r["prefill_throughput"], 1), "prefill_latency_ms": round(r["prefill_latency"] * 1e3, 2),
+                     "decode_tok_per_s": round(r["decode_throughput"], 1),
+                     "median_decode_step_ms": round(r["median_decode_latency"] * 1e3, 3)}
+    if fused is not None:
+        torch.cuda.synchronize()
+        res["fused_oproj_wait_gave_up"] = bool(int(fused.error.item()))
+        fused.close()
     return res
 
 
@@ -280,12 +324,31 @@ def collective_legs(dev, tp, rank, rehearse, fence):
         w = torch.randn((4096, k_in), device=dev, dtype=torch.bfloat16) * 0.02
         return round(timed(lambda: row_parallel_linear(x, w, chunks), reps), 2)
 
+    def fused_o_proj(T, hidden, reps):
+        from mi355_attn.tp import FusedRowParallel
+        k_in = hidden // tp
+        x = torch.randn((T, k_in), device=dev, dtype=torch.bfloat16)
+        w = torch.randn((hidden, k_in), device=dev, dtype=torch.bfloat16) * 0.02
+        f = FusedRowParallel(hidden, t_cap=256, device=dev)
+        try:
+            us = timed(lambda: f(x, w), reps)
+            y = f(x, w)
+            want = all_reduce_rows(torch.nn.functional.linear(x, w))
+            err = float((y.float() - want.float()).abs().max())
+            return {"us": round(us, 2), "max_abs_diff_vs_linear_plus_rccl": round(err, 4), "wait_gave_up": bool(int(f.error.item()))}
+        finally:
+            f.close()
+
     if rehearse:
         return {"allreduce_o_proj_llama3_8b": {"decode_B64": allreduce(64, 256, 2)},
+                "o_proj_fused_oneshot": {"T8": guarded(fused_o_proj, 8, 256, 2)},
                 "o_proj_all_reduce": {"us": {"T64": {"chunks1": o_proj(64, 1, 2), "chunks2": o_proj(64, 2, 2)}}}}
     return {
         "allreduce_o_proj_llama3_8b": {"decode_B64": allreduce(64, 4096, 50), "prefill_T4863": allreduce(4863, 4096, 10),
                                        "link_peak_GBps": "7 xGMI links x ~153 GB/s per GPU"},
+        "o_proj_fused_oneshot": {"what": "GEMM + push to all ranks over xGMI + rank-order reduce in ONE launch (m355_oproj_allreduce) "
+                                         "against o_proj_all_reduce.us.T64.chunks1 (F.linear + RCCL)",
+                                 "T64": guarded(fused_o_proj, 64, 4096, 50), "T16": guarded(fused_o_proj, 16, 4096, 50)},
         "o_proj_all_reduce": {"shape": f"x [T, {4096 // tp}] @ w [4096, {4096 // tp}]^T bf16, SUM over {tp} ranks",
                               "us": {"T64": {f"chunks{c}": o_proj(64, c, 50) for c in (1, 2)},
                                      "T4863": {f"chunks{c}": o_proj(4863, c, 10) for c in (1, 2, 4, 8)}}}}

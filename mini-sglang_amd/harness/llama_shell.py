@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 import mi355_attn as m
 from mi355_attn.rotary import RotaryEmbedding
-from mi355_attn.tp import all_reduce_rows, shard_heads
+from mi355_attn.tp import FusedRowParallel, all_reduce_rows, shard_heads
 
 
 @dataclasses.dataclass(frozen=True)
@@ -55,8 +55,11 @@ SHAPES = {
 
 class SyntheticLlama:
     def __init__(self, shape: ModelShape, tp_rank: int = 0, tp_size: int = 1, device: str = "cuda",
-                 dtype: torch.dtype = torch.bfloat16, seed: int = 0, max_position: Optional[int] = None):
+                 dtype: torch.dtype = torch.bfloat16, seed: int = 0, max_position: Optional[int] = None,
+                 fused_row_parallel: bool = False):
         self.shape, self.device, self.dtype = shape, device, dtype
+        # o_proj / down_proj + their all-reduce as one launch for decode-size inputs (TP only)
+        self.fused = FusedRowParallel(shape.hidden, t_cap=256, device=device) if fused_row_parallel and tp_size > 1 else None
         self.tp_rank, self.tp_size = tp_rank, tp_size
         self.heads = shard_heads(shape.heads, shape.kv_heads, shape.head_dim, tp_size, tp_rank)
         D, H = shape.head_dim, shape.hidden
@@ -94,6 +97,12 @@ class SyntheticLlama:
             x = x + residual
         return F.rms_norm(x, (x.shape[-1],), weight, self.shape.rms_eps), x
 
+    def _row_parallel(self, x, w):
+        """RowParallelLinear.forward (layers/linear.py:228-232)."""
+        if self.fused is not None and x.shape[0] <= self.fused.t_cap:
+            return self.fused(x if x.stride(-1) == 1 else x.contiguous(), w)
+        return all_reduce_rows(F.linear(x, w))
+
     @torch.no_grad()
     def forward(self, batch) -> torch.Tensor:
         """Hidden states of every token -> logits of each sequence's LAST token, [B, vocab]."""
@@ -107,11 +116,11 @@ class SyntheticLlama:
             k_pool, v_pool = batch.kvcache.get_kv_cache(attn.layer_id)
             self.rope.rotate_and_store(pos, q, k, v, k_pool, v_pool, loc)                 # :135 + kvcache.py:69-79
             o = batch.attn_backend.forward(q=q, k=None, v=None, layer=attn, batch=batch)  # layers/attention.py:30-36
-            x = all_reduce_rows(F.linear(o, lw["wo"]))                                     # layers/linear.py:228-232
+            x = self._row_parallel(o, lw["wo"])                                            # layers/linear.py:228-232
             h, residual = self._norm(x, residual, lw["ln2"])
             gu = F.linear(h, lw["w_gate_up"])
             gate, up = gu.chunk(2, dim=-1)
-            x = all_reduce_rows(F.linear(F.silu(gate) * up, lw["w_down"]))
+            x = self._row_parallel(F.silu(gate) * up, lw["w_down"])
         h, _ = self._norm(x, residual, self.norm)
         if batch.mode.is_prefill():
             h = h[(batch.cu_q[1:] - 1).long()]            # last new token of each sequence
@@ -123,10 +132,12 @@ class HarnessRunner:
     backend, and forward(batch) -> (logits, next_token_ids)."""
 
     def __init__(self, shape: ModelShape, page_size: int, max_total_tokens: int, max_reqs: int, context_len: int,
-                 tp_rank: int = 0, tp_size: int = 1, device: str = "cuda", dtype: torch.dtype = torch.bfloat16, seed: int = 0):
+                 tp_rank: int = 0, tp_size: int = 1, device: str = "cuda", dtype: torch.dtype = torch.bfloat16, seed: int = 0,
+                 fused_row_parallel: bool = False):
         self.device, self.page_size, self.dtype = device, page_size, dtype
         self.tp_rank, self.tp_size = tp_rank, tp_size
-        self.model = SyntheticLlama(shape, tp_rank, tp_size, device, dtype, seed, max_position=max(context_len + 8, 64))
+        self.model = SyntheticLlama(shape, tp_rank, tp_size, device, dtype, seed, max_position=max(context_len + 8, 64),
+                                    fused_row_parallel=fused_row_parallel)
         size = max_total_tokens // page_size * page_size                                    # model_runner.py:141-145
         self.kvcache = m.KVCache(size=size, page_size=page_size, head_num=self.model.heads.num_kv_heads,
                                  head_dim=shape.head_dim, dtype=dtype, layer_num=shape.layers, device=device,

@@ -6,14 +6,23 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libmi355attn.so")   # (override: dev A/B builds)
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
-# name -> (restype, argtypes); must list every symbol include/mi355attn.h declares
+MAX_RANKS = 8                        # M355_MAX_RANKS (include/mi355tp.h)
+
+
+class OprojRank(ctypes.Structure):   # M355OprojRank (include/mi355tp.h)
+    _fields_ = [("x", c_void_p), ("x_row_stride", c_int64), ("w", c_void_p), ("w_row_stride", c_int64),
+                ("out", c_void_p), ("out_row_stride", c_int64), ("recv", c_void_p * MAX_RANKS),
+                ("flags", c_void_p * MAX_RANKS), ("rank", c_int32), ("reserved", c_int32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/mi355attn.h and include/mi355tp.h declare
 SIGNATURES = {
     "m355_version": (c_int32, []),
     "m355_strerror": (c_char_p, [c_int32]),
@@ -51,6 +60,15 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_int64, c_int32,
                                     c_void_p]),
+    "m355_comm_alloc": (c_int32, [c_int64, POINTER(c_void_p)]),
+    "m355_comm_free": (c_int32, [c_void_p]),
+    "m355_comm_export": (c_int32, [c_void_p, c_void_p]),
+    "m355_comm_open": (c_int32, [c_void_p, POINTER(c_void_p)]),
+    "m355_comm_close": (c_int32, [c_void_p]),
+    "m355_oproj_recv_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "m355_oproj_flag_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "m355_oproj_allreduce": (c_int32, [POINTER(OprojRank), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32,
+                                       c_void_p, c_int32, c_void_p]),
     "m355_rope_kv_store": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                      c_int64, c_int32, c_void_p]),

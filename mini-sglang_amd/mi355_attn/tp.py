@@ -8,8 +8,9 @@ the o_proj output (layers/linear.py:228-232) - RCCL over xGMI on the GPUs ("nccl
 """
 from __future__ import annotations
 
+import ctypes
 import dataclasses
-from typing import Optional
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
@@ -85,3 +86,111 @@ def row_parallel_linear(x: torch.Tensor, w: torch.Tensor, chunks: int = 1,
     for work in pending:
         work.wait()                                            # the caller's stream waits; the host does not block on RCCL
     return y
+
+
+class FusedRowParallel:
+    """o_proj + SUM all-reduce as ONE launch per rank (include/mi355tp.h): replaces the pair
+    `F.linear(x, w)`; `dist.all_reduce(out)` of RowParallelLinear.forward (layers/linear.py:228-232) for decode-size
+    inputs (T <= t_cap rows).  A skinny matrix-core GEMM whose epilogue pushes each output tile to every rank through
+    xGMI peer pointers and adds the ranks' tiles in rank order - every rank ends with bit-identical results.
+
+    Set-up (collective over `group`, once): each rank allocates a receive buffer and a flag array in uncached device
+    memory, and the ranks swap inter-process handles with all_gather_object.  `local_world=True` instead builds EVERY
+    rank's buffers on this one device (`__call__` then takes lists, one entry per rank, and runs them in one launch):
+    the single-GPU parity test, where no second GPU exists."""
+
+    def __init__(self, out_features: int, t_cap: int = 256, group: Optional[dist.ProcessGroup] = None,
+                 local_world: int = 0, device=None):
+        from . import _lib
+        self._lib, self._L = _lib, _lib.load()
+        self.N, self.t_cap, self.epoch = int(out_features), int(t_cap), 0
+        self.local = local_world > 0
+        self.world = local_world if self.local else dist.get_world_size(group)
+        self.rank = 0 if self.local else dist.get_rank(group)
+        if not 1 <= self.world <= _lib.MAX_RANKS:
+            raise _lib.MI355AttnError(f"FusedRowParallel: world {self.world} outside [1, {_lib.MAX_RANKS}]")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        rb = self._L.m355_oproj_recv_bytes(self.world, self.t_cap, self.N)
+        fb = self._L.m355_oproj_flag_bytes(self.world, self.t_cap, self.N)
+        if rb <= 0 or fb <= 0:
+            raise _lib.MI355AttnError("FusedRowParallel: out_features must be a multiple of 64")
+        self._own: List[int] = []          # allocations of this process
+        self._opened: List[int] = []       # peers' allocations opened here
+        self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            if self.local:
+                self.recv = [self._alloc(rb) for _ in range(self.world)]
+                self.flags = [self._alloc(fb) for _ in range(self.world)]
+                return
+            mine = (self._alloc(rb), self._alloc(fb))
+            handles = [None] * self.world
+            dist.all_gather_object(handles, tuple(self._export(p) for p in mine), group=group)
+            self.recv, self.flags = [0] * self.world, [0] * self.world
+            for r, (hr, hf) in enumerate(handles):
+                self.recv[r], self.flags[r] = mine if r == self.rank else (self._open(hr), self._open(hf))
+            dist.barrier(group=group)
+
+    def _alloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._lib.check(self._L.m355_comm_alloc(nbytes, ctypes.byref(p)), "m355_comm_alloc")
+        self._own.append(p.value)
+        return p.value
+
+    def _export(self, ptr: int) -> bytes:
+        buf = ctypes.create_string_buffer(64)
+        self._lib.check(self._L.m355_comm_export(ptr, buf), "m355_comm_export")
+        return buf.raw
+
+    def _open(self, handle: bytes) -> int:
+        p = ctypes.c_void_p()
+        self._lib.check(self._L.m355_comm_open(ctypes.create_string_buffer(handle, 64), ctypes.byref(p)), "m355_comm_open")
+        self._opened.append(p.value)
+        return p.value
+
+    def close(self) -> None:
+        for p in self._opened:
+            self._L.m355_comm_close(p)
+        for p in self._own:
+            self._L.m355_comm_free(p)
+        self._opened, self._own = [], []
+
+    def _entries(self, n: int):
+        """The call's M355OprojRank array: peers' buffers filled in once, per call only x / w / out change."""
+        arr = getattr(self, "_arr", None)
+        if arr is None or len(arr) != n:
+            arr = self._arr = (self._lib.OprojRank * n)()
+            for i in range(n):
+                arr[i].rank = i if self.local else self.rank
+                for q in range(self.world):
+                    arr[i].recv[q], arr[i].flags[q] = self.recv[q], self.flags[q]
+        return arr
+
+    def __call__(self, x, w, out=None):
+        """x [T, K] and w [N, K] of this rank (lists of them, one per rank, with local_world) -> all-reduced [T, N]."""
+        xs, ws = (x, w) if self.local else ((x,), (w,))
+        T, K = xs[0].shape
+        if T > self.t_cap:
+            raise self._lib.MI355AttnError(f"FusedRowParallel: {T} rows > t_cap {self.t_cap} (use row_parallel_linear)")
+        if out is None:
+            outs = [torch.empty((T, self.N), dtype=xs[0].dtype, device=xs[0].device) for _ in xs]
+        else:
+            outs = out if self.local else (out,)
+        arr = self._entries(len(xs))
+        for e, xi, wi, oi in zip(arr, xs, ws, outs):
+            if not (xi.is_cuda and wi.is_cuda and oi.is_cuda):
+                raise self._lib.MI355AttnError("FusedRowParallel: x, w and out must live on the GPU; libmi355attn has no CPU path")
+            if xi.shape != (T, K) or wi.shape != (self.N, K) or oi.shape != (T, self.N) or xi.stride(1) != 1 or wi.stride(1) != 1 \
+                    or oi.stride(1) != 1 or xi.dtype != wi.dtype or oi.dtype != xi.dtype:
+                raise self._lib.MI355AttnError("FusedRowParallel: x [T, K], w [N, K], out [T, N], one dtype, inner stride 1")
+            e.x, e.x_row_stride, e.w, e.w_row_stride = xi.data_ptr(), xi.stride(0), wi.data_ptr(), wi.stride(0)
+            e.out, e.out_row_stride = oi.data_ptr(), oi.stride(0)
+        self.epoch += 1
+        self._lib.check(self._L.m355_oproj_allreduce(arr, len(xs), self.world, T, self.N, K, self.t_cap, self.epoch & 0xffffffff,
+                                                     self.error.data_ptr(), self._lib.dtype_code(xs[0].dtype),
+                                                     self._lib.current_stream()), "m355_oproj_allreduce")
+        return outs if self.local else outs[0]
+
+    def check(self) -> None:
+        """Raise if a wait inside any earlier call gave up (a rank never arrived).  Synchronises: tests / diagnostics."""
+        if int(self.error.item()):
+            raise self._lib.MI355AttnError("FusedRowParallel: a peer's tile never arrived (bounded wait gave up)")

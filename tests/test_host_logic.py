@@ -24,8 +24,10 @@ def _m():
 # C ABI surface
 # ------------------------------------------------------------------------------------------------
 def _declared_symbols():
-    with open(os.path.join(REPO, "include", "mi355attn.h")) as f:
-        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    text = ""
+    for header in ("mi355attn.h", "mi355tp.h"):                     # both are served by libmi355attn.so
+        with open(os.path.join(REPO, "include", header)) as f:
+            text += re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     return sorted(set(re.findall(r"\b(m355_[a-z0-9_]+)\s*\(", text)))
 
 

@@ -1,0 +1,65 @@
+"""GPU: the fused o_proj + all-reduce epilogue (include/mi355tp.h) against F.linear + SUM all-reduce
+(reference layers/linear.py:228-232).
+
+One GPU per box: every rank of the world lives on cuda:0 here (FusedRowParallel(local_world=N): all ranks' receive buffers
+and flags on this device, all ranks run in one launch), so the GEMM, the slot/flag indexing, the epoch and buffer-half
+logic and the rank-order reduction are exercised; what a single GPU cannot show is xGMI visibility of peer writes.
+Bar: the reference reduces bf16 partials (F.linear rounds, then all_reduce adds), so the expected value is the fp32
+sum of the bf16-rounded per-rank products, rounded once; the kernel adds the same rounded partials in fp32 in rank
+order -> equal up to the GEMM's own accumulation order inside a partial: atol = rtol = 2e-2 on O(1) outputs, and
+every simulated rank must hold bit-identical results."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(world, T, N, K, dtype, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    xs = [torch.randn((T, K), generator=g, device="cuda", dtype=torch.float32).to(dtype) for _ in range(world)]
+    ws = [(torch.randn((N, K), generator=g, device="cuda", dtype=torch.float32) * K ** -0.5).to(dtype) for _ in range(world)]
+    want = sum(torch.nn.functional.linear(x.float(), w.float()).to(dtype).float() for x, w in zip(xs, ws))
+    return xs, ws, want
+
+
+@pytest.mark.parametrize("world,T,N,K,dtype", [
+    (2, 64, 4096, 2048, torch.bfloat16),      # Llama-3-8B o_proj at TP=2, decode batch 64
+    (8, 64, 1024, 512, torch.bfloat16),       # TP=8 slice shape (N cut to keep all ranks' workgroups resident at once)
+    (4, 1, 2048, 1024, torch.bfloat16),       # one token
+    (4, 37, 512, 96, torch.bfloat16),         # ragged row block, K steps that do not divide over the waves
+    (2, 200, 1024, 256, torch.float16),       # several row blocks, IEEE half
+    (1, 16, 256, 64, torch.bfloat16),         # world 1: the reduction is the identity
+])
+def test_fused_oproj_matches_linear_plus_allreduce(world, T, N, K, dtype):
+    from mi355_attn.tp import FusedRowParallel
+    f = FusedRowParallel(N, t_cap=256, local_world=world, device="cuda:0")
+    try:
+        for call in range(3):                  # three calls: both buffer halves, growing epochs, a smaller batch last
+            t = T if call < 2 else max(1, T // 2)
+            xs, ws, want = _case(world, t, N, K, dtype, seed=call)
+            xs = [torch.nn.functional.pad(x, (0, 8))[:, :K] for x in xs]          # row-strided inputs (views of a wider buffer)
+            outs = f(xs, ws)
+            torch.cuda.synchronize()
+            f.check()
+            for r in range(world):
+                assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0 (call {call})"
+            torch.testing.assert_close(outs[0].float(), want, atol=2e-2, rtol=2e-2)
+    finally:
+        f.close()
+
+
+def test_fused_oproj_refuses_bad_shapes():
+    from mi355_attn import _lib
+    from mi355_attn.tp import FusedRowParallel
+    with pytest.raises(_lib.MI355AttnError):
+        FusedRowParallel(100, local_world=2, device="cuda:0")                       # N % 64
+    f = FusedRowParallel(128, t_cap=16, local_world=2, device="cuda:0")
+    try:
+        x = [torch.zeros((32, 64), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        w = [torch.zeros((128, 64), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        with pytest.raises(_lib.MI355AttnError, match="t_cap"):
+            f(x, w)
+        with pytest.raises(_lib.MI355AttnError):                                    # K % 32
+            f([t[:16, :48] for t in x], [t[:, :48] for t in w])
+    finally:
+        f.close()
