@@ -16,7 +16,8 @@
  *     head's column over all address-interleave patterns; on MI355X a CU that streams ONE 128-byte column of a
  *     contiguous pool runs up to 30 % slower on some columns;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream);
- *     no entry point synchronises, allocates or frees;
+ *     no entry point synchronises, allocates or frees, none reads the environment, and the library keeps no mutable
+ *     state (only per-device look-ups of immutable attributes: CU count, kernel attributes, the scratch address);
  *   - return value: M355_OK (0) or a negative M355_ERR_* code; nothing throws or exits;
  *   - index dtypes are the reference's: page_table int32 (memory/page_manager.py:22-24);
  *     page_table_ids / seq_lens / prefix_lens / positions / out_cache_loc int64
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define M355_VERSION 200 /* 0.2.0 */
+#define M355_VERSION 210 /* 0.2.1 */
 
 enum {
     M355_OK = 0,
@@ -44,8 +45,7 @@ enum {
 
 /* Element type of q / K / V / out.  Attention: bf16 everywhere; IEEE half (Llama-2-style fp16 checkpoints, the dtype
  * the reference takes from the checkpoint, utils/model_config.py:40-42) through the default matrix-core kernels
- * (m355_decode_attn_planned, m355_decode_store_attn_planned, m355_prefill_attn, m355_rope_kv_store); the plan-free
- * m355_decode_attn is bf16 only.  f32 is accepted by m355_kv_store alone. */
+ * (every attention entry point and m355_rope_kv_store).  f32 is accepted by m355_kv_store alone. */
 enum { M355_DTYPE_BF16 = 0, M355_DTYPE_F16 = 1, M355_DTYPE_F32 = 2 };
 
 int m355_version(void);
@@ -126,17 +126,16 @@ int m355_decode_prepare_ring(int32_t *page_table, int64_t pt_row_stride, int32_t
  * page_table[page_table_ids[b], p / page_size] * page_size + p % page_size.
  * q / out: [B, Hq*D] with row strides; pools [S, Hkv, D].  The reference always uses
  * scale = D^-0.5 (SDPA default); it is an argument here so the caller states it.
- * Long sequences are split into chunks of `chunk_tokens` (0 = choose from B, Hkv and
- * max_seq_len_hint); partial results go through `workspace` (fp32) and a merge kernel.
- * max_seq_len_hint must be >= max(seq_lens); it only sizes the grid. */
-int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t D, int32_t max_seq_len_hint,
-                                    int32_t chunk_tokens);
+ * Self-contained form, for callers without a per-forward hook: the call lays out the decode plan (m355_decode_plan, for
+ * B * max_seq_len_hint tokens) inside `workspace` and then runs m355_decode_attn_planned over it - two small launches
+ * more per call than the planned form, which shares one plan between all layers of a forward.
+ * max_seq_len_hint must be >= max(seq_lens); workspace: m355_decode_workspace_bytes, 256-byte aligned. */
+int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D, int32_t max_seq_len_hint);
 int m355_decode_attn(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
                      int64_t pool_row_stride, const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
                      const int64_t *seq_lens, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                      int32_t Hkv, int32_t D, int32_t page_size, float scale, int32_t max_seq_len_hint,
-                     int32_t chunk_tokens, void *workspace, int64_t workspace_bytes, int32_t dtype,
-                     void *stream);
+                     void *workspace, int64_t workspace_bytes, int32_t dtype, void *stream);
 
 /* Planned decode attention: the same result as m355_decode_attn, with the batch's token stream laid out
  * once per forward (the page tables are shared by all layers) and then cut into equal ranges, one per wave, so

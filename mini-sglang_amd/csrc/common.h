@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "../../include/mi355attn.h"
 
@@ -186,5 +189,34 @@ __device__ __forceinline__ void wait_tiles_younger(int younger) {
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? M355_OK : M355_ERR_LAUNCH; }
+
+// Tuning and A/B switches exist in the DEV build only (make -C csrc dev: -DM355_DEV -> lib/libmi355attn_dev.so, which
+// also holds the reference kernels and the timing probes).  The product library reads no environment variable, has one
+// path per operation and no mutable state besides per-device lookups of immutable attributes.
+#ifdef M355_DEV
+inline int dev_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline bool dev_env_set(const char* name) { return getenv(name) != nullptr; }
+inline char dev_env_char(const char* name) { const char* e = getenv(name); return e ? e[0] : '\0'; }
+#else
+inline int dev_env_int(const char*, int dflt) { return dflt; }
+inline bool dev_env_set(const char*) { return false; }
+inline char dev_env_char(const char*) { return '\0'; }
+#endif
+
+// Compute units of the CURRENT device, looked up once per device index (every launch shape follows the device it runs on).
+inline int cu_count() {
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cache[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        v = 256;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        if (v <= 0) v = 256;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 
 }  // namespace m355

@@ -13,6 +13,7 @@
 // once, an LDS round trip would only add traffic), double-buffered one iteration ahead so that each wave
 // keeps 2*U KiB of loads in flight.  Chunks of one sequence are merged by decode_merge_kernel from fp32
 // (m, l, acc) partials; sequences that fit one chunk write bf16 output directly.
+#ifdef M355_DEV      // the whole file: a dev-build A/B reference (and the row-parallel prefill of M355_PREFILL_MODE=1)
 #include <stdlib.h>
 
 #include "common.h"
@@ -500,7 +501,7 @@ extern "C" int m355dbg_set_stamp_buffer(void* dev_ptr) {      // dev-only (not p
     return hipMemcpyToSymbol(HIP_SYMBOL(m355::g_stamp_buf), &dev_ptr, sizeof(dev_ptr)) == hipSuccess ? 0 : -1;
 }
 
-extern "C" int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t D, int32_t max_seq_len_hint,
+extern "C" int64_t m355dbg_decode_chunked_workspace_bytes(int32_t B, int32_t Hq, int32_t D, int32_t max_seq_len_hint,
                                                int32_t chunk_tokens) {
     if (B <= 0 || Hq <= 0 || D <= 0 || max_seq_len_hint <= 0) return 0;
     // Hkv is not known here; size for the smallest chunk the auto rule can pick unless one is given
@@ -510,7 +511,7 @@ extern "C" int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t D,
     return (int64_t)B * Hq * splits * (D + 2) * (int64_t)sizeof(float);
 }
 
-extern "C" int m355_decode_attn(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
+extern "C" int m355dbg_decode_attn_chunked(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
                                 int64_t pool_row_stride, const int32_t* page_table, int64_t pt_row_stride, const int64_t* page_table_ids,
                                 const int64_t* seq_lens, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
                                 int32_t Hkv, int32_t D, int32_t page_size, float scale, int32_t max_seq_len_hint,
@@ -521,3 +522,4 @@ extern "C" int m355_decode_attn(const void* q, int64_t q_row_stride, const void*
                                  nullptr, nullptr, B, out, o_row_stride, B, Hq, Hkv, D, page_size, scale,
                                  max_seq_len_hint, chunk_tokens, workspace, workspace_bytes, dtype, (hipStream_t)stream);
 }
+#endif  // M355_DEV

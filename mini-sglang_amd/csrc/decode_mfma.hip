@@ -369,24 +369,17 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int cu_count() {
-    static int n = [] {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        return v > 0 ? v : 256;
-    }();
-    return n;
-}
+// Ring depth 2, up to 8 waves per CU, ranges of >= 128 tokens (4 stages; 64 and 32 measured slower); the dev build can vary them.
 static int mfma_ring() {
-    static int v = [] { const char* e = getenv("M355_MFMA_RING"); const int x = e ? atoi(e) : 2; return x < 2 ? 2 : (x > 6 ? 6 : x); }();
+    static const int v = [] { const int x = dev_env_int("M355_MFMA_RING", 2); return x < 2 ? 2 : (x > 6 ? 6 : x); }();
     return v;
 }
 static int mfma_max_wpc() {
-    static int v = [] { const char* e = getenv("M355_MFMA_WPC"); const int x = e ? atoi(e) : 8; return x < 1 ? 1 : (x > 8 ? 8 : x); }();
+    static const int v = [] { const int x = dev_env_int("M355_MFMA_WPC", 8); return x < 1 ? 1 : (x > 8 ? 8 : x); }();
     return v;
 }
-int mfma_rmin() {                                        // shortest range: 4 stages (tuning hook M355_MFMA_RMIN; 64 and 32 measured slower)
-    static int v = [] { const char* e = getenv("M355_MFMA_RMIN"); const int x = e ? atoi(e) : 128; return x < 32 ? 32 : x; }();
+int mfma_rmin() {
+    static const int v = [] { const int x = dev_env_int("M355_MFMA_RMIN", 128); return x < 32 ? 32 : x; }();
     return v;
 }
 
@@ -419,11 +412,16 @@ static int launch_mfma(const StreamParams& p, int64_t cap, hipStream_t st, bool 
         hipLaunchKernelGGL((decode_mfma_kernel<D, G, 2, false, true>), grid, block, lds, st, p, slots_cap);
         return M355_OK;
     }
+#ifdef M355_DEV
 #define M355_RING(RR) if (R == RR) { \
         if (stamp) hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, true>), grid, block, lds, st, p, slots_cap); \
         else hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, false>), grid, block, lds, st, p, slots_cap); }
     M355_RING(2) M355_RING(3) M355_RING(4) M355_RING(5) M355_RING(6)
 #undef M355_RING
+#else
+    (void)stamp;
+    hipLaunchKernelGGL((decode_mfma_kernel<D, G, 2, false>), grid, block, lds, st, p, slots_cap);
+#endif
     return M355_OK;
 }
 

@@ -616,12 +616,6 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int share_cus() {
-    int dev = 0, v = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-    return v > 0 ? v : 256;
-}
-
 ShareShape share_shape(int Hkv, int D, int G) {
     ShareShape r{0, 0, 0, 0, false};
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8) || G * D < 64 || Hkv <= 0) return r;
@@ -635,7 +629,7 @@ ShareShape share_shape(int Hkv, int D, int G) {
             const int lds = W * waveb + ns * W * pw * 4 + 64;
             if (lds <= kLds) {
                 r.W = W; r.nslot = ns; r.lds_bytes = lds; r.ok = true;
-                r.nb = share_cus() / Hkv;
+                r.nb = cu_count() / Hkv;
                 if (r.nb < 1) r.nb = 1;
                 if (r.nb > 1024) r.nb = 1024;
                 return r;
@@ -681,12 +675,16 @@ int launch_share_attn(ShareParams& p, int D, int G, bool f16, hipStream_t st, bo
     if (!sh.ok) return M355_ERR_UNSUPPORTED;
     p.nb = sh.nb; p.W = sh.W; p.nslot = sh.nslot;
     p.rot = sh.nb / p.Hkv > 0 ? sh.nb / p.Hkv : 1;
+#ifdef M355_DEV
     if (stamp && !f16 && D == 64 && G == 4) {            // dev timing build of the benchmark shape
         static bool allowed = false;
         if (!allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_share_kernel<64, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); allowed = true; }
         hipLaunchKernelGGL((decode_share_kernel<64, 4, false, true>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), sh.lds_bytes, st, p);
         return M355_OK;
     }
+#else
+    (void)stamp;
+#endif
 #define M355_CASE(DD, GG) if (D == DD && G == GG) return f16 ? launch_share<DD, GG, true>(p, sh.lds_bytes, st) : launch_share<DD, GG, false>(p, sh.lds_bytes, st);
     M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
     M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)

@@ -33,7 +33,12 @@ namespace m355 {
 // hipGetSymbolAddress returned (static_scratch() below).
 static __device__ __align__(256) unsigned char scratch[M355_STATIC_SCRATCH_BYTES];
 
-static unsigned long long* g_stream_stamps = nullptr;   // host copy of the dev-only stamp buffer pointer
+#ifdef M355_DEV
+static unsigned long long* g_stream_stamps = nullptr;   // dev build: host copy of the timing probes' buffer pointer
+#define M355_STREAM_STAMPS g_stream_stamps
+#else
+#define M355_STREAM_STAMPS nullptr
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // plan kernels
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(256) void plan_slots_kernel(const int32_t* __restri
     }
 }
 
+#ifdef M355_DEV      // ---- the VALU attention kernel over the plan: an A/B reference (M355_STREAM_KERNEL=valu), dev build only
 // ------------------------------------------------------------------------------------------------
 // attention
 // ------------------------------------------------------------------------------------------------
@@ -424,6 +430,8 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
 // NW waves per (request, q head): wave v combines partials v, v + NW, ...; the NW results meet in LDS.  NW = 1 for
 // batches whose requests are cut into a few pieces; long contexts in small batches (hundreds of pieces per request)
 // would otherwise walk them in one serial chain of memory latencies.
+#endif  // M355_DEV
+
 template <int D, int NW, bool F16 = false>
 __global__ __launch_bounds__(64 * NW) void stream_merge_kernel(const StreamParams p) {
     const int b = blockIdx.x / p.Hq;
@@ -506,17 +514,10 @@ __global__ __launch_bounds__(64 * NW) void stream_merge_kernel(const StreamParam
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int num_cus() {
-    static int n = [] {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        return v > 0 ? v : 256;
-    }();
-    return n;
-}
-// Launch shape per group size: {U, NB, waves per SIMD}.  M355_STREAM_VARIANT is a tuning hook (0 = default).
+#ifdef M355_DEV
+// Launch shape of the VALU kernel per group size: {U, NB, waves per SIMD}.  M355_STREAM_VARIANT is a tuning hook (0 = default).
 static int stream_variant() {
-    static int v = [] { const char* e = getenv("M355_STREAM_VARIANT"); return e ? atoi(e) : 0; }();
+    static const int v = dev_env_int("M355_STREAM_VARIANT", 0);
     return v;
 }
 struct StreamShape { int U, NB, W; };
@@ -533,32 +534,40 @@ static inline StreamShape stream_shape(int G) {
     }
     return v == 1 ? StreamShape{2, 4, 3} : StreamShape{2, 3, 3};
 }
-// Which attention kernel consumes the plan: the MFMA kernel (decode_mfma.hip, default) or the VALU kernel above
-// (M355_STREAM_KERNEL=valu).  The plan's waves-per-head and shortest range follow the kernel.
+// Which attention kernel consumes the plan: the matrix-core kernel (decode_mfma.hip), or in the dev build the VALU
+// kernel above (M355_STREAM_KERNEL=valu).  The plan's waves-per-head and shortest range follow the kernel.
 static bool use_mfma() {
-    static bool v = [] { const char* e = getenv("M355_STREAM_KERNEL"); return !(e && e[0] == 'v'); }();
+    static const bool v = dev_env_char("M355_STREAM_KERNEL") != 'v';
     return v;
 }
 static inline int stream_nwh(int Hkv, int D, int G, int64_t cap) {
     const int wpc = use_mfma() ? mfma_waves_per_cu(Hkv, D, G, cap) : 4 * stream_shape(G).W;
-    const int n = num_cus() * wpc / Hkv;
+    const int n = cu_count() * wpc / Hkv;
     return n < 1 ? 1 : n;
 }
 static inline int stream_rmin(int D, int G) {                                                       // >= 4 tiles per range
     return use_mfma() ? mfma_rmin() : 4 * (kWave / (D / 8)) * stream_shape(G).U;
 }
+#else
+constexpr bool use_mfma() { return true; }
+static inline int stream_nwh(int Hkv, int D, int G, int64_t cap) {
+    const int n = cu_count() * mfma_waves_per_cu(Hkv, D, G, cap) / Hkv;
+    return n < 1 ? 1 : n;
+}
+static inline int stream_rmin(int, int) { return mfma_rmin(); }
+#endif
 
 // Which kernel serves a batch: the single-launch share kernel (decode_share.hip) when, on average, a request spans at
 // most kShareSpan shares (its finishing wave combines the parts of a cut request one after the other); the per-wave
 // ranges + merge launch (decode_mfma.hip) for few, long requests (thousands of tokens per request and CU), where
 // hundreds of pieces per request want the wide merge.  Plan, workspace and attention calls all decide from the same
-// (B, head shape): M355_DECODE_SHARE=0/1 forces it (dev A/B).
+// (B, head shape); the dev build can force either with M355_DECODE_SHARE=0/1.
 constexpr int kShareSpan = 8;
 static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G) {
     if (!use_mfma()) return false;
     const ShareShape sh = share_shape(Hkv, D, G);
     if (!sh.ok) return false;
-    static const int forced = [] { const char* e = getenv("M355_DECODE_SHARE"); return e ? atoi(e) : -1; }();
+    static const int forced = dev_env_int("M355_DECODE_SHARE", -1);
     if (forced >= 0) return forced != 0;
     return (int64_t)B * kShareSpan >= sh.nb;
 }
@@ -567,10 +576,12 @@ static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G) {
 
 using namespace m355;
 
-extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev-only (not part of include/mi355attn.h)
+#ifdef M355_DEV
+extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev build only (not part of include/mi355attn.h)
     m355::g_stream_stamps = (unsigned long long*)dev_ptr;
     return 0;
 }
+#endif
 
 extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
     if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
@@ -625,11 +636,12 @@ static void launch_merge(const StreamParams& p, hipStream_t st) {
     else hipLaunchKernelGGL((stream_merge_kernel<D, 1, F16>), grid, dim3(64), 0, st, p);
 }
 
+#ifdef M355_DEV
 template <int D, int G>
 static void launch_stream(const StreamParams& p, hipStream_t st) {
     const dim3 grid((unsigned)(p.Hkv * p.nwh)), block(64);
     const StreamShape sh = stream_shape(G);
-    const bool stamp = getenv("M355_STREAM_STAMP") != nullptr;
+    const bool stamp = dev_env_set("M355_STREAM_STAMP");
 #define M355_SHAPE(UU, NN, WW) if (sh.U == UU && sh.NB == NN && sh.W == WW) { \
         if (stamp) hipLaunchKernelGGL((decode_stream_kernel<D, G, UU, NN, WW, true>), grid, block, 0, st, p); \
         else hipLaunchKernelGGL((decode_stream_kernel<D, G, UU, NN, WW>), grid, block, 0, st, p); }
@@ -639,6 +651,7 @@ static void launch_stream(const StreamParams& p, hipStream_t st) {
 #undef M355_SHAPE
     launch_merge<D>(p, st);
 }
+#endif  // M355_DEV
 
 static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
                                     int64_t pool_row_stride, void* plan, void* out, int64_t o_row_stride, int32_t B, int32_t Hq,
@@ -671,8 +684,8 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
         sp.off_stg = SL.stg; sp.off_share = SL.share; sp.off_gran = SL.gran; sp.off_rec = SL.rec;
         sp.B = B; sp.Hq = Hq; sp.Hkv = Hkv; sp.scale_log2 = scale * kLog2e;
         (void)library_scratch;
-        sp.stamps = g_stream_stamps;
-        const int rc = launch_share_attn(sp, D, G, f16, (hipStream_t)stream, getenv("M355_STREAM_STAMP") != nullptr);
+        sp.stamps = M355_STREAM_STAMPS;
+        const int rc = launch_share_attn(sp, D, G, f16, (hipStream_t)stream, dev_env_set("M355_STREAM_STAMP"));
         return rc != M355_OK ? rc : check_launch();
     }
     const int nwh = stream_nwh(Hkv, D, G, token_capacity);
@@ -688,22 +701,24 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = pool_row_stride;
     p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_rec = L.rec; p.off_slots = L.slots;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.nwh = nwh; p.max_ranges = L.max_ranges; p.scale_log2 = scale * kLog2e;
-    p.stamps = g_stream_stamps;
-    { static const int rot = [] { const char* e = getenv("M355_STREAM_ROT"); return e ? atoi(e) : 1; }();    // 0: no rotation (A/B)
+    p.stamps = M355_STREAM_STAMPS;
+    { static const int rot = dev_env_int("M355_STREAM_ROT", 1);    // (dev build, 0: no head rotation, for A/B)
       p.rot = rot ? (nwh / Hkv > 0 ? nwh / Hkv : 1) : 0; }
     hipStream_t st = (hipStream_t)stream;
     if (k_new && !use_mfma()) return M355_ERR_UNSUPPORTED;   // the fused store lives in the MFMA kernel only
     if (use_mfma()) {
-        const int rc = launch_stream_mfma(p, D, G, token_capacity, st, getenv("M355_STREAM_STAMP") != nullptr, f16);
+        const int rc = launch_stream_mfma(p, D, G, token_capacity, st, dev_env_set("M355_STREAM_STAMP"), f16);
         if (rc != M355_OK) return rc;
         if (f16) { if (D == 64) launch_merge<64, true>(p, st); else launch_merge<128, true>(p, st); }
         else { if (D == 64) launch_merge<64>(p, st); else launch_merge<128>(p, st); }
         return check_launch();
     }
+#ifdef M355_DEV
 #define M355_CASE(DD, GG) if (D == DD && G == GG) { launch_stream<DD, GG>(p, st); return check_launch(); }
     M355_CASE(64, 1) M355_CASE(64, 2) M355_CASE(64, 4) M355_CASE(64, 8)
     M355_CASE(128, 1) M355_CASE(128, 2) M355_CASE(128, 4) M355_CASE(128, 8)
 #undef M355_CASE
+#endif
     return M355_ERR_UNSUPPORTED;
 }
 
@@ -763,4 +778,36 @@ extern "C" int m355_decode_store_attn_planned(const void* q, int64_t q_row_strid
     return decode_attn_planned_impl(q, q_row_stride, k_pool, v_pool, pool_row_stride, plan, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     token_capacity, workspace, workspace_bytes, dtype, stream, k_new, k_row_stride, v_new,
                                     v_row_stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The self-contained form, for callers without a per-forward hook: lay the plan out and attend in ONE call.  The
+// workspace holds the plan (for B * max_seq_len_hint tokens, the most the batch can hold) followed by the partials.
+// ------------------------------------------------------------------------------------------------
+static inline int64_t up256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern "C" int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D, int32_t max_seq_len_hint) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || max_seq_len_hint <= 0 || Hq % Hkv) return 0;
+    const int64_t cap = (int64_t)B * max_seq_len_hint;
+    return up256(m355_decode_plan_bytes(B, Hkv, D, Hq / Hkv, cap)) + up256(m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap));
+}
+
+extern "C" int m355_decode_attn(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
+                                int64_t pool_row_stride, const int32_t* page_table, int64_t pt_row_stride,
+                                const int64_t* page_table_ids, const int64_t* seq_lens, void* out, int64_t o_row_stride,
+                                int32_t B, int32_t Hq, int32_t Hkv, int32_t D, int32_t page_size, float scale,
+                                int32_t max_seq_len_hint, void* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
+    if (B == 0) return M355_OK;
+    if (B < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || max_seq_len_hint <= 0) return M355_ERR_INVALID_ARG;
+    const int64_t cap = (int64_t)B * max_seq_len_hint;
+    if (cap > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
+    const int G = Hq / Hkv;
+    if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
+    const int64_t pb = up256(m355_decode_plan_bytes(B, Hkv, D, G, cap));
+    const int64_t wb = up256(m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap));
+    if (!workspace || workspace_bytes < pb + wb || ((uintptr_t)workspace & 255)) return M355_ERR_WORKSPACE;
+    const int rc = m355_decode_plan(seq_lens, page_table_ids, page_table, pt_row_stride, B, page_size, Hkv, D, G, cap, workspace, pb, stream);
+    if (rc != M355_OK) return rc;
+    return m355_decode_attn_planned(q, q_row_stride, k_pool, v_pool, pool_row_stride, workspace, out, o_row_stride, B, Hq, Hkv, D, scale,
+                                    cap, (char*)workspace + pb, wb, dtype, stream);
 }

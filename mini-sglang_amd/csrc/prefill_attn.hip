@@ -45,8 +45,11 @@ struct PrefillParams {
     int32_t splits;                                   // KV splits per row block (blockIdx.y)
     int32_t f16;                                      // elements are IEEE half instead of bf16
 };
-static unsigned long long* g_prefill_stamps = nullptr;
+#ifdef M355_DEV
+static unsigned long long* g_prefill_stamps = nullptr;      // dev build: timing probes (tools/stamp_prefill.py)
+#endif
 
+#ifdef M355_DEV      // ---- one wave per row tile, K/V straight from L2: an A/B reference (M355_PREFILL_MODE=2), dev build only
 template <int D>
 struct PrefillCfg {
     static constexpr int KS = D / 16;                 // k-steps of the QK^T product (16 head-dim elements each)
@@ -233,6 +236,8 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillParams p
             }
     }
 }
+
+#endif  // M355_DEV
 
 // ------------------------------------------------------------------------------------------------
 // Workgroup-shared variant (default): the 4 waves of a workgroup own 4 consecutive row tiles of one
@@ -611,8 +616,8 @@ static int ilog2_exact_p(int32_t x) {
     return s;
 }
 
-static int prefill_mode() {      // tuning / cross-check hook: 1 = row-parallel (VALU) path, 2 = one-wave-per-tile MFMA kernel
-    static int v = [] { const char* e = getenv("M355_PREFILL_MODE"); return e ? atoi(e) : 0; }();
+static int prefill_mode() {      // dev build cross-check hook: 1 = row-parallel (VALU) path, 2 = one-wave-per-tile MFMA kernel
+    static const int v = dev_env_int("M355_PREFILL_MODE", 0);
     return v;
 }
 
@@ -622,7 +627,7 @@ static int prefill_mode() {      // tuning / cross-check hook: 1 = row-parallel 
 // (splits * T * Hq <= 2^16 rows of D + 4 floats).  The same rule sizes the workspace.  (With 270 blocks - every CU
 // already busy - 4 splits measured no gain: 260 us either way; with 15 blocks 8 splits gave 319 -> 60 us.)
 static int prefill_splits(int64_t T, int32_t Hq, int32_t max_seq_len) {
-    static const int forced = [] { const char* e = getenv("M355_PREFILL_SPLITS"); return e ? atoi(e) : 0; }();   // A/B hook: 1 = never
+    static const int forced = dev_env_int("M355_PREFILL_SPLITS", 0);   // dev build A/B hook: 1 = never
     if (forced == 1) return 1;
     const int64_t blocks = (T * Hq + 127) / 128;
     int s = (int)(512 / (blocks > 0 ? blocks : 1));
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(const float* __restr
 }
 
 static int prefill_wg_cfg() {    // tuning hook: M355_PREFILL_WG = 10*waves + ring tiles/4, e.g. 41 (4 waves, 4 tiles), 42, 82
-    static int v = [] { const char* e = getenv("M355_PREFILL_WG"); return e ? atoi(e) : 0; }();
+    static const int v = dev_env_int("M355_PREFILL_WG", 0);
     return v;
 }
 
@@ -674,7 +679,8 @@ static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream
         (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, NW, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true; }();
     (void)attr_done;
-    if constexpr (D == 128 && G == 4) {                            // dev-only phase stamps (tools/stamp_prefill.py)
+#ifdef M355_DEV
+    if constexpr (D == 128 && G == 4) {                            // phase stamps (tools/stamp_prefill.py)
         if (g_prefill_stamps && p.ps_shift >= 0) {
             p.stamps = g_prefill_stamps;
             (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, NW, NBUF, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -682,6 +688,7 @@ static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream
             return;
         }
     }
+#endif
     if (p.f16) {                                                   // (default geometry only: NW = 4, 4 tile buffers)
         if constexpr (NW == 4 && NBUF == 4) {
             static bool attr16 = [] {
@@ -700,16 +707,18 @@ static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream
 
 template <int D, int G>
 static void launch_prefill_wg(const PrefillParams& p, int max_extend_len, hipStream_t st) {
+#ifdef M355_DEV
     const int cfg = p.f16 ? 0 : prefill_wg_cfg();
     if constexpr (D == 64) {
         if (cfg == 42) return launch_prefill_wg_cfg<D, G, 4, 8>(p, max_extend_len, st);
-        return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
     } else {
         if (cfg == 82) return launch_prefill_wg_cfg<D, G, 8, 8>(p, max_extend_len, st);
-        return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
     }
+#endif
+    return launch_prefill_wg_cfg<D, G, 4, 4>(p, max_extend_len, st);
 }
 
+#ifdef M355_DEV
 template <int D, int G>
 static void launch_prefill(const PrefillParams& p, hipStream_t st) {
     const int64_t items = (int64_t)p.B * p.Hkv * p.tiles_max;
@@ -718,15 +727,18 @@ static void launch_prefill(const PrefillParams& p, hipStream_t st) {
     if (p.ps_shift >= 0) hipLaunchKernelGGL((prefill_mfma_kernel<D, G, true>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((prefill_mfma_kernel<D, G, false>), grid, block, lds, st, p);
 }
+#endif
 
 }  // namespace m355
 
 using namespace m355;
 
-extern "C" int m355dbg_set_prefill_stamp_buffer(void* dev_ptr) {   // dev-only (not part of include/mi355attn.h)
+#ifdef M355_DEV
+extern "C" int m355dbg_set_prefill_stamp_buffer(void* dev_ptr) {   // dev build only (not part of include/mi355attn.h)
     m355::g_prefill_stamps = (unsigned long long*)dev_ptr;
     return 0;
 }
+#endif
 
 extern "C" int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D, int32_t max_seq_len_hint) {
     if (T <= 0 || Hq <= 0 || D <= 0 || max_seq_len_hint <= 0) return 0;
@@ -734,10 +746,13 @@ extern "C" int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D
         const int sp = prefill_splits(T, Hq, max_seq_len_hint);
         return sp > 1 ? (int64_t)T * Hq * sp * (D + 4) * (int64_t)sizeof(float) : 0;
     }
-    if (prefill_mode() != 1) return 0;
-    const int64_t splits = (max_seq_len_hint + kRowsMaxChunk - 1) / kRowsMaxChunk;
-    if (splits <= 1) return 0;
-    return (int64_t)T * Hq * splits * (D + 2) * (int64_t)sizeof(float);
+#ifdef M355_DEV
+    if (prefill_mode() == 1) {
+        const int64_t splits = (max_seq_len_hint + kRowsMaxChunk - 1) / kRowsMaxChunk;
+        return splits <= 1 ? 0 : (int64_t)T * Hq * splits * (D + 2) * (int64_t)sizeof(float);
+    }
+#endif
+    return 0;
 }
 
 extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
@@ -752,10 +767,12 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
         return M355_ERR_INVALID_ARG;
     if (pool_row_stride == 0) pool_row_stride = (int64_t)Hkv * D;
     if (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8) return M355_ERR_INVALID_ARG;
+#ifdef M355_DEV
     if (prefill_mode() == 1)        // row-parallel path: every packed query row handled like a decode query
         return paged_rows_attn(q, q_row_stride, k_pool, v_pool, pool_row_stride, page_table, pt_row_stride, page_table_ids, nullptr, cu_q,
                                prefix_lens, B, out, o_row_stride, T, Hq, Hkv, D, page_size, scale, max_seq_len_hint,
                                kRowsMaxChunk, workspace, workspace_bytes, dtype, (hipStream_t)stream);
+#endif
     const bool f16 = dtype == M355_DTYPE_F16;          // IEEE half: the workgroup kernel only
     if (dtype != M355_DTYPE_BF16 && !(f16 && prefill_mode() == 0)) return M355_ERR_UNSUPPORTED;
     if (D != 64 && D != 128) return M355_ERR_UNSUPPORTED;
@@ -786,8 +803,13 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     }
     if ((int64_t)B * Hkv * p.tiles_max > 0x7fffffffLL) return M355_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
+#ifdef M355_DEV
+#define M355_PREFILL_LAUNCH(DD, GG) if (prefill_mode() == 2) launch_prefill<DD, GG>(p, st); else launch_prefill_wg<DD, GG>(p, max_extend_len, st);
+#else
+#define M355_PREFILL_LAUNCH(DD, GG) launch_prefill_wg<DD, GG>(p, max_extend_len, st);
+#endif
 #define M355_CASE(DD, GG) if (D == DD && G == GG) { \
-        if (prefill_mode() == 2) launch_prefill<DD, GG>(p, st); else launch_prefill_wg<DD, GG>(p, max_extend_len, st); \
+        M355_PREFILL_LAUNCH(DD, GG) \
         if (p.splits > 1) { \
             const int64_t items = (int64_t)T * Hq; \
             if (f16) hipLaunchKernelGGL((prefill_merge_kernel<DD, true>), dim3((unsigned)((items * (DD / 4) + 255) / 256)), dim3(256), 0, st, \

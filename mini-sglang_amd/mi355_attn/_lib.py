@@ -9,7 +9,11 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libmi355attn.so")   # (override: dev A/B builds)
+# M355_LIB_PATH: another build of the library - tools/ and the cross-check tests point it at lib/libmi355attn_dev.so (the dev
+# build with the A/B reference kernels, M355_* switches and timing probes); "dev" is short for that path
+_DEFAULT = os.path.join(os.path.dirname(_HERE), "lib", "libmi355attn.so")
+DEV_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmi355attn_dev.so")
+LIB_PATH = {"": _DEFAULT, "dev": DEV_LIB_PATH}.get(os.environ.get("M355_LIB_PATH", ""), os.environ.get("M355_LIB_PATH"))
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
@@ -41,7 +45,7 @@ SIGNATURES = {
     "m355_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "m355_decode_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
-                                   c_int32, c_void_p, c_int64, c_int32, c_void_p]),
+                                   c_void_p, c_int64, c_int32, c_void_p]),
     "m355_decode_plan_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
     "m355_decode_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int64, c_void_p, c_int64, c_void_p]),

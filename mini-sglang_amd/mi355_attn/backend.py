@@ -13,7 +13,6 @@ with the reference's own Batch (then lengths are read back once per forward, as 
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -28,26 +27,12 @@ class ForwardMetadata:
     decode: bool
     max_seq_len: int
     max_extend_len: int = 1
-    chunk_tokens: int = 0
     plan: Optional[object] = None                  # ops.DecodePlan, decode only
     cu_q: Optional[torch.Tensor] = None            # int32 [B+1], prefill only
     workspace: Optional[torch.Tensor] = None
     ws: Optional[torch.Tensor] = None              # planned decode: the workspace of this forward ...
     ws_key: Optional[tuple] = None                 # ... and the (B, Hq, Hkv, D) it was sized for
     first_layer: Optional[int] = None              # layer_id of the first layer that used this metadata
-
-
-def pick_decode_chunk(total_tokens: int, num_kv_heads: int) -> int:
-    """Tokens per wave for decode.  One wave streams one (request, kv head, chunk); aim for ~8 waves on each
-    of the 256 CUs, keep chunks >= 128 tokens (partials cost ~G/chunk extra traffic) and <= 512 (LDS slot
-    staging).  Uses the exact token total, which the host knows."""
-    want_items = 2048
-    chunk = 512
-    while chunk > 128 and (total_tokens // chunk + 1) * num_kv_heads < want_items:
-        chunk //= 2
-    if (total_tokens // chunk + 1) * num_kv_heads < 512:
-        chunk = 64
-    return chunk
 
 
 class MI355AttnBackend:
@@ -58,12 +43,11 @@ class MI355AttnBackend:
         self._workspace: Optional[torch.Tensor] = None
         self._plan_buf: Optional[torch.Tensor] = None
         self._plan_key = None
-        # "planned": per-forward plan + stream-split kernel (default); "chunked": self-contained m355_decode_attn
-        self.decode_mode = os.environ.get("M355_DECODE_MODE", "planned")
-        # planned decode on the matrix-core kernel can write the step's K/V rows itself (one launch less per layer)
-        self.fused_store = (os.environ.get("M355_STREAM_KERNEL", "mfma")[:1] != "v"
-                            and os.environ.get("M355_DECODE_FUSED_STORE", "1") != "0")
-        self._num_kv_heads_hint = getattr(getattr(model_runner, "kvcache", None), "head_num", None)
+        # decode: one plan per forward shared by all layers (m355_decode_plan) + one attention launch per layer that also
+        # writes the step's K/V rows (m355_decode_store_attn_planned).  fused_store = False keeps the separate
+        # m355_kv_store launch (cross-check tests).
+        self.decode_mode = "planned"
+        self.fused_store = True
         # planned decode: lay the plan out for at least this many tokens (a captured decode step needs every kernel
         # argument - the plan's layout among them - to stay the same while the batch grows)
         self.decode_capacity_hint = 0
@@ -81,9 +65,7 @@ class MI355AttnBackend:
         if lens is None:
             lens = [int(x) for x in batch.seq_lens.tolist()]          # one sync, like flash_attention_backend.py:60
         if batch.mode.is_decode():
-            hkv = self._num_kv_heads_hint or batch.kvcache.head_num
-            self.forward_metadata = ForwardMetadata(decode=True, max_seq_len=max(lens),
-                                                    chunk_tokens=pick_decode_chunk(sum(lens), hkv))
+            self.forward_metadata = ForwardMetadata(decode=True, max_seq_len=max(lens))
             self._plan_key = (batch, sum(lens))       # the plan itself needs the layer's head shape: built lazily
             return
         pre = getattr(batch, "prefix_lens_host", None)
@@ -126,28 +108,22 @@ class MI355AttnBackend:
             md.first_layer = layer.layer_id
         k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
         B = q.shape[0]
-        fuse = (self.decode_mode == "planned" and self.fused_store and k is not None and k.dtype == k_pool.dtype
+        fuse = (self.fused_store and k is not None and k.dtype == k_pool.dtype
                 and v.dtype == v_pool.dtype and k.stride(-1) == 1 and v.stride(-1) == 1)
         if not fuse:
             self._store_kv(k, v, layer, batch)
-        if self.decode_mode == "planned":
-            Hq, Hkv, D = layer.num_heads, layer.num_kv_heads, layer.head_dim
-            if md.plan is None:                        # first layer of this forward: lay the token stream out once
-                cap = max(self._plan_key[1], int(self.decode_capacity_hint))
-                md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
-                                          self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
-                self._plan_buf = md.plan.buf
-            ws = md.ws                                 # sized once per forward (same shape in every layer)
-            if ws is None or md.ws_key != (B, Hq, Hkv, D):
-                ws = md.ws = self._ws(ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity), q.device)
-                md.ws_key = (B, Hq, Hkv, D)
-            return ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws,
-                                           k_new=k if fuse else None, v_new=v if fuse else None)
-        ws = self._ws(ops.decode_workspace_bytes(B, layer.num_heads, layer.head_dim, md.max_seq_len, md.chunk_tokens),
-                      q.device)
-        return ops.decode_attn(q.reshape(B, layer.num_heads * layer.head_dim), k_pool, v_pool,
-                               batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens, self.page_size,
-                               layer.num_heads, md.max_seq_len, chunk_tokens=md.chunk_tokens, workspace=ws)
+        Hq, Hkv, D = layer.num_heads, layer.num_kv_heads, layer.head_dim
+        if md.plan is None:                        # first layer of this forward: lay the token stream out once
+            cap = max(self._plan_key[1], int(self.decode_capacity_hint))
+            md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
+                                      self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
+            self._plan_buf = md.plan.buf
+        ws = md.ws                                 # sized once per forward (same shape in every layer)
+        if ws is None or md.ws_key != (B, Hq, Hkv, D):
+            ws = md.ws = self._ws(max(256, ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity)), q.device)
+            md.ws_key = (B, Hq, Hkv, D)
+        return ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws,
+                                       k_new=k if fuse else None, v_new=v if fuse else None)
 
     def forward_extend(self, q, k, v, layer, batch):
         md = self.forward_metadata

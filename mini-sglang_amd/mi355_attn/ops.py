@@ -171,15 +171,17 @@ def decode_prepare_ring(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: 
     return trio[0], trio[1], trio[2]
 
 
-def decode_workspace_bytes(B: int, Hq: int, D: int, max_seq_len: int, chunk_tokens: int = 0) -> int:
-    return int(_lib.load().m355_decode_workspace_bytes(B, Hq, D, max_seq_len, chunk_tokens))
+def decode_workspace_bytes(B: int, Hq: int, Hkv: int, D: int, max_seq_len: int) -> int:
+    return int(_lib.load().m355_decode_workspace_bytes(B, Hq, Hkv, D, max_seq_len))
 
 
 def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, page_table: torch.Tensor,
                 page_table_ids: torch.Tensor, seq_lens: torch.Tensor, page_size: int, num_heads: int,
-                max_seq_len: int, scale: float | None = None, chunk_tokens: int = 0,
+                max_seq_len: int, scale: float | None = None,
                 workspace: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Paged decode attention (reference torch_native_backend.py:121-193).  q [B, Hq*D] (row-strided ok)."""
+    """Paged decode attention (reference torch_native_backend.py:121-193), self-contained: the call lays its own plan out
+    (callers with a per-forward hook use decode_plan + decode_attn_planned and share the plan between layers).
+    q [B, Hq*D] (row-strided ok)."""
     lib = _lib.load()
     for n, t in (("q", q), ("k_pool", k_pool), ("v_pool", v_pool), ("page_table", page_table),
                  ("page_table_ids", page_table_ids), ("seq_lens", seq_lens)):
@@ -194,15 +196,15 @@ def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, pag
         out = torch.empty((B, Hq * D), dtype=q.dtype, device=q.device)
     if scale is None:
         scale = float(D) ** -0.5          # SDPA default: the reference never passes layer.scale on
-    need = decode_workspace_bytes(B, Hq, D, max_seq_len, chunk_tokens)
-    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+    need = decode_workspace_bytes(B, Hq, Hkv, D, max_seq_len)
+    if workspace is None or workspace.numel() * workspace.element_size() < need or workspace.data_ptr() % 256:
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
-    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    ws_bytes = workspace.numel() * workspace.element_size()
     assert page_table.dtype == torch.int32 and page_table_ids.dtype == torch.int64 and seq_lens.dtype == torch.int64
     check(lib.m355_decode_attn(q2.data_ptr(), q2.stride(0), k_pool.data_ptr(), v_pool.data_ptr(), pool_pitch(k_pool, v_pool),
                                page_table.data_ptr(),
                                page_table.stride(0), page_table_ids.data_ptr(), seq_lens.data_ptr(), out.data_ptr(),
-                               out.stride(0), B, Hq, Hkv, D, page_size, scale, max_seq_len, chunk_tokens,
+                               out.stride(0), B, Hq, Hkv, D, page_size, scale, max_seq_len,
                                _ptr(workspace), ws_bytes, dtype_code(q.dtype), current_stream()), "m355_decode_attn")
     return out
 

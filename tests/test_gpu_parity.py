@@ -228,10 +228,10 @@ def test_decode_attn_split_and_merge(Hq, Hkv, D, ps):
                            torch.tensor(lens), None, ps).reshape(B, Hq * D).float().numpy()
     dq, dk, dv = q.to(DEV), kp.to(DEV), vp.to(DEV)
     dt, dr, dl = torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV)
-    for chunk in (0, 64, 128, 256, 512):
-        o = ops.decode_attn(dq, dk, dv, dt, dr, dl, ps, Hq, max(lens), chunk_tokens=chunk)
+    for hint in (max(lens), max(lens) + 500):         # the self-contained call: its own plan, laid out for B * hint tokens
+        o = ops.decode_attn(dq, dk, dv, dt, dr, dl, ps, Hq, hint)
         torch.cuda.synchronize()
-        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"chunk={chunk}")
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"hint={hint}")
     for cap in (sum(lens), sum(lens) + 1000):
         plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, cap)
         o = ops.decode_attn_planned(dq, dk, dv, plan, Hq)
@@ -343,10 +343,9 @@ def test_decode_attn_softmax_spike():
     kp[slot] = 4.0                                      # q.k = 4*64 -> towers over N(0, 8) scores
     ref = A.paged_attn_f64(q.view(1, Hq, D), kp, vp, torch.from_numpy(table), torch.from_numpy(rows),
                            torch.tensor(lens), None, ps).reshape(1, -1).float().numpy()
-    for chunk in (64, 512):
-        o = ops.decode_attn(q.to(DEV), kp.to(DEV), vp.to(DEV), torch.from_numpy(table).to(DEV),
-                            torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV), ps, Hq, 500, chunk_tokens=chunk)
-        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    o = ops.decode_attn(q.to(DEV), kp.to(DEV), vp.to(DEV), torch.from_numpy(table).to(DEV),
+                        torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV), ps, Hq, 500)
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
     plan = ops.decode_plan(torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV), torch.tensor(lens, device=DEV),
                            ps, Hq, Hkv, D, 500)
     o = ops.decode_attn_planned(q.to(DEV), kp.to(DEV), vp.to(DEV), plan, Hq)
@@ -472,7 +471,7 @@ def test_decode_cfg2_full_size_properties():
     vp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
     q = torch.randn((B, Hq * D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
     dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
-    outs = [ops.decode_attn(q, kp, vp, dt, dr, dl, ps, Hq, max(lens), chunk_tokens=c).float() for c in (0, 128, 512)]
+    outs = [ops.decode_attn(q, kp, vp, dt, dr, dl, ps, Hq, hint).float() for hint in (max(lens), 2 * max(lens))]
     outs.append(ops.decode_attn_planned(q, kp, vp, ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens)), Hq).float())
     for o in outs[1:]:
         assert torch.allclose(o, outs[0], rtol=BF16_RTOL, atol=BF16_ATOL)
@@ -493,8 +492,14 @@ def test_random_configurations_sweep():
     splits through planned decode with fused store, chunked decode and prefill, against torch fp32 on the GPU."""
     import subprocess
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py")
-    for extra, share in (([], "0"), (["f16"], "0"), ([], "1"), (["f16"], "1")):   # bf16 / IEEE half; both decode kernels
+    # bf16 / IEEE half on the product library (it picks the decode kernel from the batch shape), then the dev build with
+    # each decode kernel FORCED onto every batch (M355_DECODE_SHARE), so both see shapes the rule would not give them
+    from mi355_attn import _lib
+    runs = [([], {}), (["f16"], {})]
+    if os.path.exists(_lib.DEV_LIB_PATH):
+        runs += [(x, {"M355_LIB_PATH": "dev", "M355_DECODE_SHARE": s}) for s in ("0", "1") for x in ([], ["f16"])]
+    for extra, env in runs:
         r = subprocess.run([sys.executable, tool, "1", "5"] + extra, capture_output=True, text=True, timeout=110,
-                           env=dict(os.environ, M355_DECODE_SHARE=share))
+                           env=dict(os.environ, **env))
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         assert "random configurations passed" in r.stdout

@@ -20,6 +20,7 @@ STREAM = os.environ.get("STAMP_STREAM") == "1"
 if STREAM:
     os.environ["M355_STREAM_VARIANT"] = "0"
     os.environ["M355_STREAM_STAMP"] = "1"
+os.environ.setdefault("M355_LIB_PATH", "dev")      # timing probes live in the dev build (make -C mini-sglang_amd/csrc dev)
 import mi355_attn as m  # noqa: E402
 from mi355_attn import _lib, ops  # noqa: E402
 

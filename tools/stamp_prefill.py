@@ -13,6 +13,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "mini-sglang_amd"))
+os.environ.setdefault("M355_LIB_PATH", "dev")      # timing probes live in the dev build (make -C mini-sglang_amd/csrc dev)
 from mi355_attn import _lib, ops  # noqa: E402
 
 dev = "cuda:0"

@@ -17,6 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "mini-sglang_amd"))
 os.environ["M355_STREAM_STAMP"] = "1"
 os.environ.setdefault("M355_DECODE_SHARE", "1")
+os.environ.setdefault("M355_LIB_PATH", "dev")      # timing probes live in the dev build (make -C mini-sglang_amd/csrc dev)
 import mi355_attn as m  # noqa: E402
 from mi355_attn import _lib, ops  # noqa: E402
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep on the GPU (dev): planned decode (+fused store), chunked decode and prefill against a torch
+"""Randomised parity sweep on the GPU (dev): planned decode (+fused store), self-contained decode and prefill against a torch
 fp32 reference on the same device, over random head shapes, page sizes, batch compositions and prefix splits."""
 import os
 import sys
@@ -80,9 +80,8 @@ while time.time() - t0 < budget:
     assert torch.equal(kp3, kp2) and torch.equal(vp3, vp2), f"fused store pools differ: {tag}"
     err = float((o.float() - ref).abs().max())
     assert torch.allclose(o.float(), ref, rtol=TOL, atol=TOL), f"planned decode {tag}: {err}"
-    if DT == torch.bfloat16:                             # the plan-free chunked kernels are bf16 only
-        o = ops.decode_attn(q, kp2, vp2, dt, dr, dl, ps, Hq, max(seq))
-        assert torch.allclose(o.float(), ref, rtol=TOL, atol=TOL), f"chunked decode {tag}"
+    o = ops.decode_attn(q, kp2, vp2, dt, dr, dl, ps, Hq, max(seq))      # the self-contained call (its own plan)
+    assert torch.allclose(o.float(), ref, rtol=TOL, atol=TOL), f"self-contained decode {tag}"
     # ---- prefill over random page-aligned prefixes
     pre = [int(rng.integers(0, l)) // ps * ps for l in seq]
     ext = [s - p for s, p in zip(seq, pre)]
