@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restri
         const int32_t a = max(sb0, s0), e = min(sb1, s1);                     // the segment = this request's stages in the share
         const int32_t st = v - a, seg_n = e - a;
         const int32_t sl = (s1 - e) + st;                                     // the share's segments are walked last to first
-        int32_t* rec = plan + L.rec + (int64_t)(s0 + sl) * kRecW;
+        int32_t* rec = plan + L.rec + ((int64_t)i * L.qcap + sl) * kRecW;
         const int32_t pg = tok / ps;
         const int32_t slot = page_table[rows[b] * pt_stride + pg] * ps + (tok - pg * ps);
         rec[idx] = slot;
@@ -236,11 +236,19 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
     const int share = blockIdx.x / p.Hkv;
     // heads rotate over the XCDs (workgroups are dealt round-robin to them): see decode_mfma.hip
     const int h = (blockIdx.x + (p.rot > 0 ? share / p.rot : 0)) % p.Hkv;
+    // a streaming wave's first two stage records sit at places known from the kernel arguments alone: asked for at once,
+    // they travel beside the header loads below instead of behind them
+    const int32_t* const grec = p.plan + p.off_rec + ((int64_t)share * p.qcap + (wave < W ? wave : 0)) * kRecW;
+    const uint32_t rec0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem) + (wave < W ? wave : 0) * S::WAVEB + 2 * M::STAGEB;
+    if (wave < W && lane < kRecW) {
+        glds4(grec + lane, rec0);
+        glds4(grec + (int64_t)W * kRecW + lane, rec0 + S::RECBYTES);
+    }
     const int Q = __builtin_amdgcn_readfirstlane(p.plan[kHShareStages]);
     const int TS = __builtin_amdgcn_readfirstlane(p.plan[kHStages]);
     const int SO = share * Q;                                        // the share = stages [SO, SO + NS) of the stream
     const int NS = TS - SO < Q ? TS - SO : Q;
-    if (NS <= 0) return;
+    if (NS <= 0) { wait_vmcnt<0>(); return; }                        // (no LDS-DMA may outlive its wave)
     shstamp<STAMP>(p, wave, 1);
 
     if (wave == W) {
@@ -334,22 +342,35 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             asm volatile("" ::: "memory");
             if (ord == 0) shstamp<STAMP>(p, wave, 2);
             if (b == bf) shstamp<STAMP>(p, wave, 4);
+            // all partials of the segment are requested at once (one LDS latency, not one per wave: a share of many short
+            // requests merges a segment every few hundred cycles, and its streaming waves wait for their partial slots)
             const float* slot = parts + (ord % p.nslot) * W * S::PW;
-            float gm = kNegBig;
-            for (int t = 0; t < e; ++t) {
-                int w = first + t; w = w >= W ? w - W : w;
-                gm = fmaxf(gm, slot[w * S::PW + G * D + g]);
+            constexpr int WMAX = share_max_waves(D);
+            float pm[WMAX], pl[WMAX], pa[WMAX][VEC];
+#pragma unroll
+            for (int w = 0; w < WMAX; ++w) {
+                int rel = w - first;
+                rel += rel < 0 ? W : 0;
+                const bool part = w < W && rel < e;                  // wave w streamed a piece of this segment
+                const float* pw = slot + (part ? w : first) * S::PW;
+                const float m_ = pw[G * D + g], l_ = pw[G * D + G + g];
+#pragma unroll
+                for (int x = 0; x < VEC; ++x) pa[w][x] = part ? pw[e0 + x] : 0.f;
+                pm[w] = part ? m_ : kNegBig;
+                pl[w] = part ? l_ : 0.f;
             }
+            float gm = pm[0];
+#pragma unroll
+            for (int w = 1; w < WMAX; ++w) gm = fmaxf(gm, pm[w]);
             float den = 0.f, acc[VEC];
 #pragma unroll
             for (int x = 0; x < VEC; ++x) acc[x] = 0.f;
-            for (int t = 0; t < e; ++t) {
-                int w = first + t; w = w >= W ? w - W : w;
-                const float* pw = slot + w * S::PW;
-                const float wgt = exp2_fast(pw[G * D + g] - gm);
-                den = fmaf(wgt, pw[G * D + G + g], den);
 #pragma unroll
-                for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, pw[e0 + x], acc[x]);
+            for (int w = 0; w < WMAX; ++w) {
+                const float wgt = exp2_fast(pm[w] - gm);             // (absent waves: 2^(-1e30 - gm) = 0 on zeros)
+                den = fmaf(wgt, pl[w], den);
+#pragma unroll
+                for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, pa[w][x], acc[x]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) {                                         // slot free: count back to zero first, then release
@@ -409,16 +430,14 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
 
     // ============================================================================================ streaming wave
     const int j = wave;
-    if (j >= NS) { __syncthreads(); return; }
+    if (j >= NS) { wait_vmcnt<0>(); __syncthreads(); return; }
     const int Nw = (NS - j + W - 1) / W;                                // this wave's stages: j, j + W, ...
     uint8_t* const wbase = smem + j * S::WAVEB;
     uint8_t* const ringp = wbase;
     const int32_t* const recr = reinterpret_cast<const int32_t*>(wbase + 2 * M::STAGEB);
     uint8_t* const qbuf = wbase + 2 * M::STAGEB + 4 * S::RECBYTES;
     const uint32_t ring0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ringp);
-    const uint32_t rec0 = ring0 + 2 * M::STAGEB;
     const uint32_t q0 = rec0 + 4 * S::RECBYTES;
-    const int32_t* const grec = p.plan + p.off_rec + (int64_t)(SO + j) * kRecW;
 
     const int n = lane & 15;                             // q column / K row / d column, by operand
     const int kg = lane >> 4;                            // 16-lane group = k sub-block
@@ -595,8 +614,6 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
     // One stage per wave in flight (eight per CU): measured as fast as two, with half the spread between the waves of
     // a workgroup, and every wait is a plain vmcnt(0).  The ring has two slots so that stage s+1 can be asked for as
     // soon as stage s has landed, before it is consumed.
-    rec_dma(0);
-    rec_dma(1);
     __syncthreads();                                     // ctl is zero for everyone (nothing reads it before a first flush)
     wait_vmcnt<0>();
     shstamp<STAMP>(p, wave, 2);

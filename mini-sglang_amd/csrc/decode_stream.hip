@@ -681,7 +681,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
         sp.k_new = (const uint16_t*)k_new; sp.v_new = (const uint16_t*)v_new; sp.kn_stride = k_row_stride; sp.vn_stride = v_row_stride;
         sp.plan = (int32_t*)plan; sp.out = (uint16_t*)out;
         sp.q_stride = q_row_stride; sp.o_stride = o_row_stride; sp.row_elems = pool_row_stride;
-        sp.off_stg = SL.stg; sp.off_share = SL.share; sp.off_gran = SL.gran; sp.off_rec = SL.rec;
+        sp.off_stg = SL.stg; sp.off_share = SL.share; sp.off_gran = SL.gran; sp.off_rec = SL.rec; sp.qcap = SL.qcap;
         sp.B = B; sp.Hq = Hq; sp.Hkv = Hkv; sp.scale_log2 = scale * kLog2e;
         (void)library_scratch;
         sp.stamps = M355_STREAM_STAMPS;

@@ -26,10 +26,13 @@ constexpr int kHTotal = 0, kHShareStages = 1, kHB = 2, kHShares = 3, kHWaves = 4
 // hand-off granules per (kv head, share): one fp32 partial O[G][D] + m, l per lane, 8 bytes {value, tag} each
 __host__ __device__ inline int64_t share_gran_words(int D, int G) { return (int64_t)((G * D / 64 > 0 ? G * D / 64 : 1) + 2) * 64 * 2; }
 
-// plan buffer (int32 words): hdr | cum[B+1] | stg[B+1] | nz[B+1] | share[nb][kShareW] | gran[Hkv*nb][...] | rec[max_stages][kRecW]
+// plan buffer (int32 words): hdr | cum[B+1] | stg[B+1] | nz[B+1] | share[nb][kShareW] | gran[Hkv*nb][...] | rec[nb][qcap][kRecW]
+// Share i's records start at a place that depends on i alone (i * qcap), so a wave asks for its first records with its
+// very first instructions, beside the header loads that tell it how many stages the share really has.
 struct ShareLayout {
     int64_t cum, stg, nz, share, gran, gran_words, rec, ints;
     int64_t max_stages;
+    int32_t qcap;                                   // record places per share (>= the stages any share can get)
 };
 __host__ __device__ inline ShareLayout share_layout(int32_t B, int32_t nb, int32_t Hkv, int64_t cap, int32_t D, int32_t G) {
     ShareLayout L;
@@ -41,7 +44,9 @@ __host__ __device__ inline ShareLayout share_layout(int32_t B, int32_t nb, int32
     L.gran = (L.share + (int64_t)nb * kShareW + 63) & ~(int64_t)63;
     L.gran_words = (int64_t)Hkv * nb * share_gran_words(D, G);
     L.rec = (L.gran + L.gran_words + 63) & ~(int64_t)63;                   // records start on a 256-byte line
-    L.ints = L.rec + L.max_stages * kRecW;
+    int64_t q = (L.max_stages + nb - 1) / nb;
+    L.qcap = (int32_t)(q < kShareMinStages ? kShareMinStages : q);
+    L.ints = L.rec + ((int64_t)nb * L.qcap + 2 * kShareMaxWaves) * kRecW;  // (+ slack: a wave's first two record fetches are unconditional)
     return L;
 }
 
@@ -63,7 +68,7 @@ struct ShareParams {
     uint16_t* out;
     int64_t q_stride, o_stride, row_elems;
     int64_t off_stg, off_share, off_gran, off_rec;
-    int32_t B, Hq, Hkv, nb, W, nslot, rot;
+    int32_t B, Hq, Hkv, nb, W, nslot, rot, qcap;
     float scale_log2;
     unsigned long long* stamps;   // dev-only timing probe (tools/stamp_share.py), 8 slots per wave; else nullptr
 };
