@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)h * W::ROWB;
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)h * W::ROWB;
-    const int64_t row_bytes = p.row_elems * 2;
+    const uint32_t row_bytes = (uint32_t)(p.row_elems * 2);       // (< 2^32: a token row is at most a few KiB)
     // slots of tokens [win*kSlotWin, +kSlotWin) -> LDS (ordinary loads: the compiler's wait drains the DMA queue too,
     // once per 32 KV tiles)
     int cur_win = -1;
@@ -387,11 +387,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
             sl[x] = slotw[((tile * 32) & (kSlotWin - 1)) + (wid + NW * (x % HP)) * W::RPI + drow];
         }
     };
+    // per-lane byte offsets of the 16-byte chunk inside a token row (K and V swizzles), one per DMA row block of this wave
+    uint32_t kch[HP], vch[HP];
+#pragma unroll
+    for (int y = 0; y < HP; ++y) {
+        const int row = (wid + NW * y) * W::RPI + drow;
+        kch[y] = 16 * (dch ^ W::sK(row));
+        vch[y] = 16 * (dch ^ W::sV(row));
+    }
     auto piece = [&](const bool is_v, const int x, const int32_t slot, const int buf0) {
         const int i = wid + NW * (x % HP);                         // wave-uniform
-        const int row = i * W::RPI + drow;
-        const int ch = dch ^ (is_v ? W::sV(row) : W::sK(row));
-        glds16p<M355_PREFILL_POLICY>((is_v ? vbase : kbase) + (int64_t)slot * row_bytes + 16 * ch,
+        // slot * row_bytes + chunk: ONE v_mad_u64_u32 (32 x 32 -> 64 bits), not a 64 x 64 product
+        const uint64_t off = (uint64_t)(uint32_t)slot * row_bytes + (is_v ? vch[x % HP] : kch[x % HP]);
+        glds16p<M355_PREFILL_POLICY>((is_v ? vbase : kbase) + off,
                lds0 + (is_v ? NBUF * W::TILEB : 0) + (buf0 + x / HP) * W::TILEB + 1024 * i);
     };
     auto issue_pair = [&](const int pair, const int buf0) {         // prologue: everything at once
@@ -502,10 +510,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         // the pair NP-1 ahead goes into the buffers that pair k-1 vacated (slots now, DMA further down)
         constexpr int nb = 2 * ((pb + NP - 1) % NP);
         int32_t sl[IPW];
-        pair_slots(k + NP - 1, sl);
-        stamp(1);
         const int base_a = 64 * k, base_b = 64 * k + 32;
         if (base_a >= kv_end) {                                    // wave-uniform: the row tile is past its diagonal
+            pair_slots(k + NP - 1, sl);
 #pragma unroll
             for (int x = 0; x < IPW; ++x) { piece(false, x, sl[x], nb); piece(true, x, sl[x], nb); }
             return;
@@ -514,6 +521,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         f32x16 sa, sb;
 #pragma unroll
         for (int s = 0; s < W::KS; ++s) fa[s] = rdk(2 * pb, s);
+        // the slot look-ups queue up behind the K fragments: their LDS latency passes under the QK^T MFMAs instead of in
+        // front of them (they are first needed by the K pieces below)
+        pair_slots(k + NP - 1, sl);
+        stamp(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
