@@ -16,7 +16,7 @@ import sqlite3
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -105,6 +105,14 @@ if os.path.exists(ppmc):
                               "GRBM_GUI_ACTIVE -- python3 tools/bench_prefill.py --layers 2 --reps 2 (averages per launch)",
                    "kernels": vals}, f, indent=1)
     print(json.dumps(vals, indent=1))
+for name in ("variants.jsonl", "prefill.json"):            # measured lines, copied as they are
+    path = os.path.join(src, name)
+    if os.path.exists(path):
+        with open(path) as f, open(os.path.join(dst, f"{tag}_{'decode_variants.jsonl' if name.startswith('variants') else 'prefill_lines.jsonl'}"), "w") as g:
+            g.write(f.read())
+if bench is not None:
+    with open(os.path.join(dst, f"{tag}_bench_full.json"), "w") as f:
+        json.dump(bench, f, indent=1)
 for k, e in traffic.items():
     print(k[:90], e.get("hbm_read_bytes_per_launch"), e.get("hbm_write_bytes_per_launch"))
 for n, c, t, a, lo, hi in rows[:8]:
