@@ -278,10 +278,12 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
         // The hand-off runs BESIDE the segment loop and never makes it wait: a publisher's partial travels as 8-byte
         // granules {value, tag}, each written by ONE write-through store, so there is no flag and no ordering to wait
         // for; this wave loads the next publisher's granules in one call of cross_step and looks at them kCrossLag calls
-        // later, when they have long landed (a global access of a streaming CU takes ~4 us; a wave stalled on it would
-        // not see its own streaming waves arrive, and they would wait for their partial slot).  All tags raised: the
-        // partial is folded into (cm, cl, cacc) and its granules are lowered again for the next launch.
-        constexpr int kCrossLag = 20;
+        // later (a wave stalled on a global access of a streaming CU would not see its own streaming waves arrive).
+        // All tags raised: the partial is folded into (cm, cl, cacc) and its granules are lowered again for the next
+        // launch.  Measured on configs[1] (one box, stamps): with a lag of 20 polls a load -> look cycle takes ~2.5 us
+        // and 112 of 248 merging workgroups finished their hand-off AFTER their last stage (+1.4 us); lag 6: 21, lag 2:
+        // 10, tail p95 2.4 -> 1.5 us - and the same launch time, which the slowest streaming waves set.
+        constexpr int kCrossLag = 4;
         int cstate = 0, cage = 0;
         unsigned long long cg[NG];
 #pragma unroll
