@@ -137,6 +137,9 @@ class GraphedDecode:
             batch.advance_host_for_decode()
             with torch.cuda.graph(self.graph):
                 self._device_step()
+            # the captured kernels hold raw pointers into the backend's workspace and plan buffer: no other forward may
+            # replace them while this graph lives (a bigger prefill or batch then raises instead of freeing them)
+            runner.attn_backend.buffers_pinned = True
             self.graph.replay()
             self.taken += 1
 
@@ -158,6 +161,13 @@ class GraphedDecode:
 
     def tokens(self) -> torch.Tensor:
         return self.out[:, : self.taken]
+
+    def release(self) -> None:
+        """Drop the captured graph; the backend may size its buffers freely again."""
+        torch.cuda.synchronize()
+        self.graph = None
+        self.runner.attn_backend.buffers_pinned = False
+        self.runner.attn_backend.decode_capacity_hint = 0
 
 
 def reset_pools(runner):
@@ -182,7 +192,9 @@ def three_phase(runner, prompts, cut_len: int, output_len: int, graph: bool = Fa
         g = GraphedDecode(next_ids, batch, runner, output_len - 1)
         while g.taken < output_len - 1:
             g.next()
-        return logits, torch.cat([next_ids.unsqueeze(1), g.tokens()], dim=1)
+        toks = torch.cat([next_ids.unsqueeze(1), g.tokens()], dim=1)
+        g.release()
+        return logits, toks
     out = [next_ids]
     for _ in range(output_len - 1):
         next_ids, _ = decode(next_ids, batch, runner)
@@ -240,6 +252,7 @@ def latency_test(runner, bench_args: BenchArgs, bs: int, il: int, ol: int, rank_
                 g.next()
                 sync()
                 steps.append(time.perf_counter() - t0)
+            g.release()
             total_decode = sum(steps) / len(steps) * (ol - 1)        # the two set-up steps priced as replayed steps
         else:
             setup = None

@@ -42,6 +42,9 @@ class MI355AttnBackend:
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._workspace: Optional[torch.Tensor] = None
         self._plan_buf: Optional[torch.Tensor] = None
+        # set while a captured HIP graph holds raw pointers into _workspace / _plan_buf (bench_one_batch.GraphedDecode):
+        # replacing either buffer would leave the graph replaying against freed memory, so growth is refused instead
+        self.buffers_pinned = False
         self._plan_key = None
         # decode: one plan per forward shared by all layers (m355_decode_plan) + one attention launch per layer that also
         # writes the step's K/V rows (m355_decode_store_attn_planned).  fused_store = False keeps the separate
@@ -57,6 +60,9 @@ class MI355AttnBackend:
         if nbytes == 0:
             return None
         if self._workspace is None or self._workspace.numel() < nbytes:
+            if self.buffers_pinned:
+                raise ops._lib.MI355AttnError("MI355AttnBackend: a captured graph pins the workspace; this forward needs a "
+                                              "bigger one (release the graph first: GraphedDecode.release())")
             self._workspace = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
         return self._workspace
 
@@ -117,6 +123,9 @@ class MI355AttnBackend:
             cap = max(self._plan_key[1], int(self.decode_capacity_hint))
             md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
                                       self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
+            if self.buffers_pinned and md.plan.buf is not self._plan_buf:
+                raise ops._lib.MI355AttnError("MI355AttnBackend: a captured graph pins the plan buffer; this forward needs a "
+                                              "bigger one (release the graph first: GraphedDecode.release())")
             self._plan_buf = md.plan.buf
         ws = md.ws                                 # sized once per forward (same shape in every layer)
         if ws is None or md.ws_key != (B, Hq, Hkv, D):

@@ -27,6 +27,8 @@ def test_three_phase_matches_single_shot(model, ps, cut):
     logits1, ids1 = bob.three_phase(runner, prompts, 0, out_len)
     scale = float(logits1.float().abs().max())
     assert torch.isfinite(logits3).all() and scale > 0
+    # (a smoke bar for the harness plumbing - cut + extend against a single shot through random weights; the parity
+    # evidence for the kernels is tests/test_gpu_parity.py and tests/test_gpu_configs.py, against the pinned oracle)
     assert float((logits3.float() - logits1.float()).abs().max()) <= 0.05 * scale
     assert torch.equal(ids3[:, 0], ids1[:, 0]) or float((ids3 == ids1).float().mean()) > 0.8
 
@@ -90,6 +92,13 @@ def test_graphed_decode_equals_the_eager_loop(model, ps):
     _, graphed = bob.three_phase(runner, prompts, 0, out_len, graph=True)
     assert torch.equal(eager, graphed)
     assert runner.kvcache.ring.snapshot() == runner.kvcache.free_pages
+    # while a graph lives the backend refuses to replace the buffers its kernels point into; released, it may again
+    be = runner.attn_backend
+    assert not be.buffers_pinned
+    be.buffers_pinned = True
+    with pytest.raises(RuntimeError, match="pins the workspace"):
+        be._ws(be._workspace.numel() * 4 if be._workspace is not None else 1 << 20, "cuda")
+    be.buffers_pinned = False
 
 
 def test_three_phase_in_half_precision():
