@@ -19,32 +19,11 @@
 // K/V of the new tokens are read back from the pool (the KV write precedes this kernel on the stream).
 #include <stdlib.h>
 
-#include "common.h"
+#include "prefill_common.h"
 #include "paged_rows.h"
 
-#ifndef M355_PREFILL_POLICY
-#define M355_PREFILL_POLICY 0     // K/V tiles are re-read by the row blocks of the same XCD through L2: default policy
-#endif
 namespace m355 {
 
-struct PrefillParams {
-    const uint16_t* q;
-    const uint16_t* k_pool;
-    const uint16_t* v_pool;
-    const int32_t* page_table;
-    const int64_t* page_table_ids;
-    const int64_t* seq_lens;
-    const int64_t* prefix_lens;
-    const int32_t* cu_q;
-    uint16_t* out;
-    int64_t q_stride, o_stride, pt_stride, row_elems;
-    int32_t B, Hq, Hkv, ps, ps_shift, tiles_max;
-    float scale_log2;
-    unsigned long long* stamps;                       // dev-only: per-wave phase cycle sums (STAMP builds)
-    float* ws;                                        // split-KV partials [T*Hq rows][splits][D + 4: O, m, l, pad] (splits > 1)
-    int32_t splits;                                   // KV splits per row block (blockIdx.y)
-    int32_t f16;                                      // elements are IEEE half instead of bf16
-};
 #ifdef M355_DEV
 static unsigned long long* g_prefill_stamps = nullptr;      // dev build: timing probes (tools/stamp_prefill.py)
 #endif
@@ -247,30 +226,6 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillParams p
 // ds_read_b64_tr_b16 transposed reads.  L2->CU traffic drops by 4 against one-wave-per-tile streaming, which was
 // what bounded the first kernel (3.3 GB per layer on the 8B shared-prefix workload).
 // ------------------------------------------------------------------------------------------------
-template <int D>
-struct WgCfg {
-    static constexpr int C = D / 8;                   // 16-byte chunks per row
-    static constexpr int ROWB = 2 * D;
-    static constexpr int RPI = 64 / C;                // rows per DMA instruction
-    static constexpr int NI = 32 / RPI;               // DMA instructions per K (or V) tile
-    static constexpr int TILEB = 32 * ROWB;
-    static constexpr int BUFB = 2 * TILEB;            // K tile then V tile
-    static constexpr int KS = D / 16, DT = D / 32;
-    static constexpr int SPAN = 16 / C;               // rows per 256-byte bank span
-    // chunk ch of row `row` sits at position ch ^ s(row): conflict-free 16-row ds_read_b128 column reads of K,
-    // conflict-free 4-row x 64-byte transposed reads of V
-    __device__ static constexpr int sK(int row) { return (row / SPAN) % C; }
-    __device__ static constexpr int sV(int row) { return ((row / SPAN) % (C / 4)) * 4; }
-};
-
-template <int V> struct IntC { static constexpr int value = V; };
-#ifndef M355_PREFILL_PRIO
-#define M355_PREFILL_PRIO 2
-#endif
-constexpr int kPrio = M355_PREFILL_PRIO;          // s_setprio 1 around the MFMA clusters: 1 = QK^T only, 2 = PV too (each +1-2 % on cfg3, A/B on one box)
-constexpr float kLazy = 8.f;                          // log2 units
-constexpr int kSlotWin = 1024;                        // tokens whose pool slots are staged in LDS at a time
-
 template <int D, int G, int NW, int NBUF, bool POW2, bool STAMP = false, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(const PrefillParams p) {
     using W = WgCfg<D>;
@@ -716,6 +671,12 @@ static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream
     else hipLaunchKernelGGL((prefill_wg_kernel<D, G, NW, NBUF, false>), grid, block, lds, st, p);
 }
 
+#ifdef M355_DEV
+// The dev build can route head_dim 128 to the 64-rows-per-wave kernel of prefill_wg2.hip (M355_PREFILL_RT=2).  It is at
+// parity with prefill_wg_kernel, not ahead, so the product has one kernel and does not link the other.
+static bool prefill_use_wg2(int D) { return D == 128 && dev_env_int("M355_PREFILL_RT", 1) == 2; }
+#endif
+
 template <int D, int G>
 static void launch_prefill_wg(const PrefillParams& p, int max_extend_len, hipStream_t st) {
 #ifdef M355_DEV
@@ -815,7 +776,8 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     if ((int64_t)B * Hkv * p.tiles_max > 0x7fffffffLL) return M355_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
 #ifdef M355_DEV
-#define M355_PREFILL_LAUNCH(DD, GG) if (prefill_mode() == 2) launch_prefill<DD, GG>(p, st); else launch_prefill_wg<DD, GG>(p, max_extend_len, st);
+#define M355_PREFILL_LAUNCH(DD, GG) if (prefill_mode() == 2) launch_prefill<DD, GG>(p, st); \
+        else if (!(prefill_use_wg2(DD) && launch_prefill_wg2(p, DD, GG, max_extend_len, st))) launch_prefill_wg<DD, GG>(p, max_extend_len, st);
 #else
 #define M355_PREFILL_LAUNCH(DD, GG) launch_prefill_wg<DD, GG>(p, max_extend_len, st);
 #endif

@@ -498,6 +498,8 @@ def test_random_configurations_sweep():
     runs = [([], {}), (["f16"], {})]
     if os.path.exists(_lib.DEV_LIB_PATH):
         runs += [(x, {"M355_LIB_PATH": "dev", "M355_DECODE_SHARE": s}) for s in ("0", "1") for x in ([], ["f16"])]
+        # ... and the dev-only 64-rows-per-wave prefill kernel on every head_dim-128 extend (csrc/prefill_wg2.hip)
+        runs += [([], {"M355_LIB_PATH": "dev", "M355_PREFILL_RT": "2"})]
     for extra, env in runs:
         r = subprocess.run([sys.executable, tool, "1", "5"] + extra, capture_output=True, text=True, timeout=110,
                            env=dict(os.environ, **env))
