@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling passes)")
+    ap.add_argument("--fused-probe", action="store_true", help="internal: child of an N>1 run, see fused_probe()")
     ap.add_argument("--heads", type=str, default="", help="experiment: Hq,Hkv,D per GPU instead of the 1B shape")
     ap.add_argument("--copies", type=int, default=0, help="experiment: batch = 64 * copies")
     ap.add_argument("--fixed-len", type=int, default=0, help="experiment: every request has this length (with --batch)")
@@ -80,6 +81,8 @@ def main():
     ap.add_argument("--len-scale", type=int, default=1, help="experiment: every length x this (SURVEY 8d cfg2 'long' variant: 8)")
     args = ap.parse_args()
 
+    if args.fused_probe:
+        sys.exit(fused_probe_child())
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,9 +199,16 @@ def guarded(fn, *a, **k):
         torch.cuda.empty_cache()
 
 
+def note(rank, msg):
+    """Progress on stderr (rank 0): the run prints its one stdout line only at the end."""
+    if rank == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def extras(dev, tp, rank, rehearse, fence) -> dict:
     from harness import workloads as W
     out = {}
+    note(rank, "headline measured; side measurements: decode shapes")
     if tp == 1:
         # the 8B head shape on the same batch as the headline (SURVEY §8 table: (32, 8, 128))
         out["decode_8b_shape"] = guarded(W.decode_shape_report, dev, 32, 8, 128, W.cfg2_lengths(1), 16)
@@ -209,15 +219,73 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
         out["decode_cfg5_per_rank"]["note"] = ("per-rank shape of Llama-3-70B at TP=8, context 32 768, page_size 16, "
                                                + ("one rank of 8 measured" if tp == 8 else "measured on one GPU"))
     # cfg3 / cfg4: Llama-3-8B prefill over shared cached prefixes, this rank's heads
+    note(rank, "prefill cfg3")
     out["prefill_cfg3" if tp == 1 else "prefill_cfg3_per_rank"] = guarded(prefill_cfg3, dev, tp)
-    out["bench_one_batch_llama3_8b"] = guarded(one_batch, dev, tp, rank, rehearse)
+    note(rank, "fused o_proj probe (child processes)" if tp > 1 else "bench_one_batch")
+    fused_ok = tp > 1 and fused_probe(dev, tp)
     if tp > 1:
-        out.update(guarded(collective_legs, dev, tp, rank, rehearse, fence))
+        out["o_proj_fused_probe"] = "ok" if fused_ok else "failed in its child processes: the fused legs below were skipped"
+    if tp > 1:
+        note(rank, f"probe {'ok' if fused_ok else 'FAILED'}; bench_one_batch")
+    out["bench_one_batch_llama3_8b"] = guarded(one_batch, dev, tp, rank, rehearse, fused_ok)
+    note(rank, "bench_one_batch done")
+    if tp > 1:
+        out.update(guarded(collective_legs, dev, tp, rank, rehearse, fence, fused_ok))
     if tp == 1:
         out["o_proj_fused_single_gpu"] = guarded(o_proj_single_gpu, dev)
     if tp == 1 and rank == 0:
         out["cpu_baseline_cfg1"] = guarded(cpu_baseline_cfg1)
     return out
+
+
+def fused_probe(dev, tp) -> bool:
+    """The one-launch o_proj + reduce writes through peer pointers, and a bad peer mapping is a GPU memory fault, which no
+    `except` catches.  So its first run across these GPUs happens in CHILD processes (one per rank, their own gloo group
+    on the next port, same devices): if a child faults, gives up waiting or disagrees with the plain sum, the ranks of
+    this run skip the fused legs and the bench line survives."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}   # (the children keep their own store)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 23)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused-probe"], env=env, capture_output=True, text=True,
+                           timeout=240)
+        ok = r.returncode == 0 and "FUSED_PROBE_OK" in r.stdout
+    except Exception:           # noqa: BLE001  (timeout, spawn failure)
+        ok = False
+    flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def fused_probe_child() -> int:
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = 0 if os.environ.get("M355_BENCH_REHEARSE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    import datetime
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))
+    from mi355_attn.tp import FusedRowParallel
+    hidden, T = 4096, 64
+    g = torch.Generator(device=dev).manual_seed(77 + rank)
+    x = torch.randn((T, hidden // world), generator=g, device=dev).to(torch.bfloat16)
+    w = (torch.randn((hidden, hidden // world), generator=g, device=dev) * 0.02).to(torch.bfloat16)
+    f = FusedRowParallel(hidden, t_cap=256, device=dev)
+    try:
+        for _ in range(3):                                  # epochs, both buffer halves
+            y = f(x, w)
+        torch.cuda.synchronize()
+        want = torch.nn.functional.linear(x, w).float().cpu()
+        dist.all_reduce(want)
+        err = float((y.float().cpu() - want).abs().max())
+        gave_up = int(f.error.item())
+        dist.barrier()
+    finally:
+        f.close()
+    dist.destroy_process_group()
+    if gave_up or not err < 0.05:
+        print(f"FUSED_PROBE_FAILED rank {rank}: max diff {err}, wait gave up {gave_up}", flush=True)
+        return 1
+    print("FUSED_PROBE_OK", flush=True)
+    return 0
 
 
 def o_proj_single_gpu(dev):
@@ -261,7 +329,7 @@ def prefill_cfg3(dev, tp):
     return r
 
 
-def one_batch(dev, tp, rank, rehearse):
+def one_batch(dev, tp, rank, rehearse, fused_ok=False):
     """bench_one_batch's latency mode (reference bench_one_batch.py:72-84, 195-214) on Llama-3-8B with synthetic weights:
     B=64, input 1024, 32 output tokens; tok/s = B * decode steps / sum(decode step time).  TP=N under torch.distributed."""
     import bench_one_batch as ob
@@ -270,7 +338,7 @@ def one_batch(dev, tp, rank, rehearse):
     bs, il, ol = (4, 64, 8) if rehearse else (64, 1024, 32)
     shape = SHAPES[model]
     runner = HarnessRunner(shape, PAGE_SIZE, max_total_tokens=bs * (il + ol + 2 * PAGE_SIZE) + 64 * PAGE_SIZE, max_reqs=bs,
-                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=tp, device=dev, fused_row_parallel=tp > 1)
+                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=tp, device=dev, fused_row_parallel=fused_ok)
     quiet = lambda *a, **k: None      # noqa: E731
     res = {"model": shape.name, "weights": "synthetic", "dtype": "bf16", "tp_size": tp, "batch_size": bs, "input_len": il,
            "output_len": ol, "page_size": PAGE_SIZE}
@@ -278,7 +346,7 @@ def one_batch(dev, tp, rank, rehearse):
     # TP=1: the eager loop and the captured-graph loop; TP=N: RCCL all-reduce after o_proj / down_proj, and the same run
     # with the two as fused GEMM + one-shot reduce launches for the decode steps
     for name, graph, use_fused in ((("eager", False, False), ("graph", True, False)) if tp == 1 else
-                                   (("eager_rccl", False, False), ("eager_fused_oproj", False, True))):
+                                   (("eager_rccl", False, False),) + ((("eager_fused_oproj", False, True),) if fused_ok else ())):
         runner.model.fused = fused if use_fused else None
         r = ob.latency_test(runner, ob.BenchArgs(graph=graph, model=model), bs, il, ol, quiet, tp)
         res[name] = {"prefill_tok_per_s": round(r["prefill_throughput"], 1), "prefill_latency_ms": round(r["prefill_latency"] * 1e3, 2),
@@ -291,7 +359,7 @@ def one_batch(dev, tp, rank, rehearse):
     return res
 
 
-def collective_legs(dev, tp, rank, rehearse, fence):
+def collective_legs(dev, tp, rank, rehearse, fence, fused_ok=False):
     """The layer's one exchange step, outside the path (layers/linear.py:228-232): RCCL all-reduce of the o_proj output at
     the decode and prefill sizes of Llama-3-8B, and o_proj GEMM + all-reduce back to back against the
     f3 variants (mi355_attn.tp)."""
@@ -326,6 +394,8 @@ def collective_legs(dev, tp, rank, rehearse, fence):
 
     def fused_o_proj(T, hidden, reps):
         from mi355_attn.tp import FusedRowParallel
+        if not fused_ok:
+            return {"skipped": "o_proj_fused_probe failed"}
         k_in = hidden // tp
         x = torch.randn((T, k_in), device=dev, dtype=torch.bfloat16)
         w = torch.randn((hidden, k_in), device=dev, dtype=torch.bfloat16) * 0.02
