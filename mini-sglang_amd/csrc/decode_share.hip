@@ -695,11 +695,14 @@ int launch_share_attn(ShareParams& p, int D, int G, bool f16, hipStream_t st, bo
     p.nb = sh.nb; p.W = sh.W; p.nslot = sh.nslot;
     p.rot = sh.nb / p.Hkv > 0 ? sh.nb / p.Hkv : 1;
 #ifdef M355_DEV
-    if (stamp && !f16 && D == 64 && G == 4) {            // dev timing build of the benchmark shape
-        static bool allowed = false;
-        if (!allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_share_kernel<64, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); allowed = true; }
-        hipLaunchKernelGGL((decode_share_kernel<64, 4, false, true>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), sh.lds_bytes, st, p);
-        return M355_OK;
+    if (stamp && !f16) {                                   // dev timing builds: the benchmark shape, the 8B and the 70B/TP8 per-rank shape
+#define M355_STAMPED(DD, GG) if (D == DD && G == GG) { \
+            static bool allowed = false; \
+            if (!allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_share_kernel<DD, GG, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); allowed = true; } \
+            hipLaunchKernelGGL((decode_share_kernel<DD, GG, false, true>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), sh.lds_bytes, st, p); \
+            return M355_OK; }
+        M355_STAMPED(64, 4) M355_STAMPED(128, 4) M355_STAMPED(128, 8)
+#undef M355_STAMPED
     }
 #else
     (void)stamp;

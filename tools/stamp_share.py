@@ -25,10 +25,16 @@ dev = "cuda:0"
 Hq, Hkv, D, ps, L = 32, 8, 64, 16, 4
 random.seed(0)
 lens = [random.randint(64, 2048) + 1 for _ in range(64)]
+CUSTOM = "STAMP_SHAPE" in os.environ                 # e.g. STAMP_SHAPE=8,1,128 STAMP_LENS=32768x32: the summary only
+if CUSTOM:
+    Hq, Hkv, D = (int(x) for x in os.environ["STAMP_SHAPE"].split(","))
+    n_, b_ = os.environ.get("STAMP_LENS", "32768x32").split("x")
+    lens = [int(n_) + 1] * int(b_)
+    L = 2
 B = len(lens)
 pages = sum(-(-l // ps) for l in lens) + 8
 kv = m.KVCache(pages * ps, ps, Hkv, D, torch.bfloat16, L, dev, row_pad=int(os.environ['ROW_PAD']) if 'ROW_PAD' in os.environ else None)
-pm = m.PageManager(ps, B, 4096, dev)
+pm = m.PageManager(ps, B, max(4096, max(lens) + ps), dev)
 kv._free = deque(torch.randperm(pages, generator=torch.Generator().manual_seed(0)).tolist())
 kv._store.copy_(torch.randn(kv._store.shape, device=dev).to(torch.bfloat16))
 reqs = [m.Req(i, list(range(l))) for i, l in enumerate(lens)]
@@ -37,7 +43,7 @@ for r in reqs:
 batch = m.Batch(reqs, pm, kv, device=dev)
 batch.prepare_for_prefill()
 q = torch.randn((B, Hq * D), device=dev).to(torch.bfloat16)
-NW = 9
+NW = 9                              # stamp rows per workgroup: kShareMaxWaves + 1
 nblocks = 256
 stamps = torch.zeros((nblocks * NW, 8), dtype=torch.int64, device=dev)
 lib = _lib.load()
@@ -45,6 +51,7 @@ setter = lib.m355dbg_set_stream_stamp_buffer
 setter.argtypes = [ctypes.c_void_p]
 assert setter(stamps.data_ptr()) == 0
 plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens))
+WS = int(plan.buf.view(torch.int32)[4].item())      # streaming waves per workgroup; the finishing wave is wave WS
 
 
 def run(layer):
@@ -62,9 +69,9 @@ torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.int64).reshape(nblocks, NW, 8)
 us = lambda x: x * 0.01
 t0 = s[:, :, 0][s[:, :, 0] > 0].min()
-st = s[:, :8].reshape(-1, 8)
+st = s[:, :WS].reshape(-1, 8)
 st = st[st[:, 5] > 0]
-hp = s[:, 8]
+hp = s[:, WS]
 hp = hp[hp[:, 5] > 0]
 print(f"streaming waves {len(st)}, finishing waves {len(hp)}")
 for name, a in (("streaming", st), ("finishing", hp)):
@@ -80,6 +87,18 @@ loop = st[:, 4] - st[:, 3]
 print(f"streaming loop (first stage landed -> last issued): median {us(np.median(loop)):.2f} p95 {us(np.percentile(loop,95)):.2f} max {us(loop.max()):.2f}")
 hdr = plan.buf.view(torch.int32)[:8].cpu().numpy()
 print("plan header: total", hdr[0], "share stages", hdr[1], "shares", hdr[3], "waves", hdr[4], "stages", hdr[5], "error", hdr[6])
+wg_end_ = (s[:, :WS, 5] - t0).max(axis=1) * 0.01
+print("workgroup end percentiles (streaming waves)", [round(float(np.percentile(wg_end_, q)), 2) for q in (5, 25, 50, 75, 95, 100)])
+fin_end = (s[:, WS, 5] - t0) * 0.01
+print("finishing wave end percentiles", [round(float(np.percentile(fin_end[fin_end > 0], q)), 2) for q in (5, 25, 50, 75, 95, 100)])
+if CUSTOM:
+    f = s[:, WS]
+    for k, name in ((2, "first segment's waves arrived"), (3, "hand-off complete"), (4, "last segment's waves arrived"), (5, "done")):
+        ok = f[:, k] > 0
+        if ok.any():
+            d = (f[ok, k] - t0) * 0.01
+            print(f"[finishing] {name}: n={ok.sum()} median {np.median(d):.2f} p5 {np.percentile(d,5):.2f} p95 {np.percentile(d,95):.2f} max {d.max():.2f}")
+    sys.exit(0)
 # ---- where does the spread come from: wave index, XCD slot, workgroup
 S5 = (s[:, :8, 5] - t0) * 0.01
 S3 = (s[:, :8, 3] - t0) * 0.01
