@@ -98,6 +98,21 @@ if CUSTOM:
         if ok.any():
             d = (f[ok, k] - t0) * 0.01
             print(f"[finishing] {name}: n={ok.sum()} median {np.median(d):.2f} p5 {np.percentile(d,5):.2f} p95 {np.percentile(d,95):.2f} max {d.max():.2f}")
+    if Hkv == 1:                     # long requests: how long after its LAST publisher's stores does a merger complete?
+        rows = []
+        for b in range(nblocks):
+            if f[b, 3] == 0:
+                continue
+            pubs = [q for q in range(max(0, b - 16), b) if f[q, 7] > 0]
+            k = 0
+            while b - 1 - k >= 0 and f[b - 1 - k, 7] > 0 and k < 16:
+                k += 1
+            if k == 0:
+                continue
+            last_pub = max(f[b - 1 - i, 7] for i in range(k))
+            rows.append((k, (last_pub - t0) * 0.01, (f[b, 4] - t0) * 0.01, (f[b, 3] - t0) * 0.01, (f[b, 5] - t0) * 0.01))
+        for r in rows[:40]:
+            print("   publishers %d: last stored %.2f | merger: own last arrival %.2f, hand-off complete %.2f, done %.2f" % r)
     sys.exit(0)
 # ---- where does the spread come from: wave index, XCD slot, workgroup
 S5 = (s[:, :8, 5] - t0) * 0.01
