@@ -558,18 +558,22 @@ static inline int stream_rmin(int, int) { return mfma_rmin(); }
 #endif
 
 // Which kernel serves a batch: the single-launch share kernel (decode_share.hip) when, on average, a request spans at
-// most kShareSpan shares (its finishing wave combines the parts of a cut request one after the other); the per-wave
-// ranges + merge launch (decode_mfma.hip) for few, long requests (thousands of tokens per request and CU), where
-// hundreds of pieces per request want the wide merge.  Plan, workspace and attention calls all decide from the same
-// (B, head shape); the dev build can force either with M355_DECODE_SHARE=0/1.
+// most kShareSpan shares (its finishing wave combines the parts of a cut request one after the other) AND a share is
+// at least kShareMinBytes of K/V: below that the launch is a few microseconds of streaming and the publish -> fetch
+// chains of cut requests outlast it (measured, dev build, both kernels forced: (8,1,128) B=64 at 148 KB per share 20.8 us
+// against 17.2 for ranges + merge; ties from 300 to 600 KB; the share kernel ahead by 3-8 % from 600 KB up).  The
+// per-wave ranges + merge launch (decode_mfma.hip) serves the rest: small launches, and few long requests (thousands of
+// tokens per request and CU), where hundreds of pieces per request want the wide merge.  Plan, workspace and attention
+// calls all decide from the same (B, head shape, token_capacity); the dev build can force either with M355_DECODE_SHARE=0/1.
 constexpr int kShareSpan = 8;
-static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G) {
+constexpr int64_t kShareMinBytes = 512 * 1024;
+static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
     if (!use_mfma()) return false;
     const ShareShape sh = share_shape(Hkv, D, G);
     if (!sh.ok) return false;
     static const int forced = dev_env_int("M355_DECODE_SHARE", -1);
     if (forced >= 0) return forced != 0;
-    return (int64_t)B * kShareSpan >= sh.nb;
+    return (int64_t)B * kShareSpan >= sh.nb && token_capacity * 4 * D >= (int64_t)sh.nb * kShareMinBytes;
 }
 
 }  // namespace m355
@@ -585,7 +589,7 @@ extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev build o
 
 extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
     if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
-    if (share_mode(B, Hkv, D, G))
+    if (share_mode(B, Hkv, D, G, token_capacity))
         return share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G).ints * (int64_t)sizeof(int32_t);
     return plan_layout(B, stream_nwh(Hkv, D, G, token_capacity), token_capacity).ints * (int64_t)sizeof(int32_t);
 }
@@ -598,7 +602,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
         return M355_ERR_INVALID_ARG;
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
     if (token_capacity > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
-    if (share_mode(B, Hkv, D, G)) {
+    if (share_mode(B, Hkv, D, G, token_capacity)) {
         const ShareLayout SL = share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G);
         if (plan_bytes < SL.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
         return launch_share_plan(seq_lens, page_table_ids, page_table, pt_row_stride, B, page_size, Hkv, D, G, token_capacity,
@@ -620,7 +624,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
 extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                                        int64_t token_capacity) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return 0;
-    if (share_mode(B, Hkv, D, Hq / Hkv)) return 0;      // single launch: partials never leave LDS (hand-offs ride in the plan)
+    if (share_mode(B, Hkv, D, Hq / Hkv, token_capacity)) return 0;      // single launch: partials never leave LDS (hand-offs ride in the plan)
     const PlanLayout L = plan_layout(B, stream_nwh(Hkv, D, Hq / Hkv, token_capacity), token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;      // every range boundary and request adds at most one
     return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
@@ -673,7 +677,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
         return M355_ERR_INVALID_ARG;
     if (pool_row_stride == 0) pool_row_stride = (int64_t)Hkv * D;
     if (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8) return M355_ERR_INVALID_ARG;
-    if (share_mode(B, Hkv, D, G)) {
+    if (share_mode(B, Hkv, D, G, token_capacity)) {
         const ShareShape sh = share_shape(Hkv, D, G);
         const ShareLayout SL = share_layout(B, sh.nb, Hkv, token_capacity, D, G);
         ShareParams sp;
