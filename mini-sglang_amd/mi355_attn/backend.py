@@ -35,6 +35,33 @@ class ForwardMetadata:
     first_layer: Optional[int] = None              # layer_id of the first layer that used this metadata
 
 
+_NATIVE_GROUPS = (1, 2, 4, 8)          # query heads per kv head the kernels are built for
+
+
+def _group_pad(num_heads: int, num_kv_heads: int) -> int:
+    """The group size the kernels run a layer at.  The reference takes any Llama config (utils/model_config.py:24-47); the
+    HIP kernels are built for groups of 1, 2, 4 and 8 query heads per kv head, so any other group (Llama-3.2-3B: 24 / 8 = 3;
+    Yi-34B: 56 / 8 = 7) runs in the next one up with all-zero query heads appended to every group - their outputs are
+    dropped - at (padded / real) times the attention arithmetic and two small copies per layer."""
+    if num_heads % num_kv_heads:
+        raise ops._lib.MI355AttnError(f"MI355AttnBackend: {num_heads} query heads are not a multiple of {num_kv_heads} kv heads")
+    g = num_heads // num_kv_heads
+    for n in _NATIVE_GROUPS:
+        if n >= g:
+            return n
+    raise ops._lib.MI355AttnError(f"MI355AttnBackend: {g} query heads per kv head (at most {_NATIVE_GROUPS[-1]} are supported)")
+
+
+def _pad_groups(q: torch.Tensor, Hkv: int, G: int, Gp: int, D: int) -> torch.Tensor:
+    T = q.shape[0]
+    return torch.nn.functional.pad(q.reshape(T, Hkv, G, D), (0, 0, 0, Gp - G)).view(T, Hkv * Gp * D)
+
+
+def _drop_pad(o: torch.Tensor, Hkv: int, G: int, Gp: int, D: int) -> torch.Tensor:
+    T = o.shape[0]
+    return o.view(T, Hkv, Gp, D)[:, :, :G].reshape(T, Hkv * G * D)
+
+
 class MI355AttnBackend:
     def __init__(self, model_runner):
         self.device = model_runner.device
@@ -119,6 +146,9 @@ class MI355AttnBackend:
         if not fuse:
             self._store_kv(k, v, layer, batch)
         Hq, Hkv, D = layer.num_heads, layer.num_kv_heads, layer.head_dim
+        G, Gp = Hq // Hkv, _group_pad(Hq, Hkv)
+        if Gp != G:
+            q, Hq = _pad_groups(q.reshape(B, Hq * D), Hkv, G, Gp, D), Hkv * Gp
         if md.plan is None:                        # first layer of this forward: lay the token stream out once
             cap = max(self._plan_key[1], int(self.decode_capacity_hint))
             md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
@@ -131,8 +161,9 @@ class MI355AttnBackend:
         if ws is None or md.ws_key != (B, Hq, Hkv, D):
             ws = md.ws = self._ws(max(256, ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity)), q.device)
             md.ws_key = (B, Hq, Hkv, D)
-        return ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws,
-                                       k_new=k if fuse else None, v_new=v if fuse else None)
+        o = ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws,
+                                    k_new=k if fuse else None, v_new=v if fuse else None)
+        return o if Gp == G else _drop_pad(o, Hkv, G, Gp, D)
 
     def forward_extend(self, q, k, v, layer, batch):
         md = self.forward_metadata
@@ -143,7 +174,11 @@ class MI355AttnBackend:
         self._store_kv(k, v, layer, batch)       # first: the new tokens' K/V are read back from the pool
         k_pool, v_pool = batch.kvcache.get_kv_cache(layer.layer_id)
         T = q.shape[0]
-        ws = self._ws(ops.prefill_workspace_bytes(T, layer.num_heads, layer.head_dim, md.max_seq_len), q.device)
-        return ops.prefill_attn(q, k_pool, v_pool, batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
-                                batch.prefix_lens, md.cu_q, self.page_size, layer.num_heads, md.max_extend_len,
-                                md.max_seq_len, workspace=ws)
+        Hq, Hkv, D = layer.num_heads, layer.num_kv_heads, layer.head_dim
+        G, Gp = Hq // Hkv, _group_pad(Hq, Hkv)
+        if Gp != G:
+            q, Hq = _pad_groups(q, Hkv, G, Gp, D), Hkv * Gp
+        ws = self._ws(ops.prefill_workspace_bytes(T, Hq, D, md.max_seq_len), q.device)
+        o = ops.prefill_attn(q, k_pool, v_pool, batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
+                             batch.prefix_lens, md.cu_q, self.page_size, Hq, md.max_extend_len, md.max_seq_len, workspace=ws)
+        return o if Gp == G else _drop_pad(o, Hkv, G, Gp, D)

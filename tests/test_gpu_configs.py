@@ -85,6 +85,64 @@ def test_cfg1_1b_ps1_prompt128_then_16_decode_steps():
 
 
 # ------------------------------------------------------------------------------------------------
+# group sizes the kernels are not built for (the reference takes any Llama config, utils/model_config.py:24-47)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Hq,Hkv,D", [(24, 8, 128), (6, 2, 64), (7, 1, 128), (5, 1, 64)],
+                         ids=["llama32_3b_G3", "G3_D64", "yi34b_tp8_G7", "G5"])
+def test_group_sizes_outside_1_2_4_8(Hq, Hkv, D):
+    """Llama-3.2-3B has 24 query heads on 8 kv heads (G = 3), Yi-34B 56 on 8 (G = 7): the backend runs such layers in the
+    next built group size with zero query heads appended.  Three ragged requests prefilled at page_size 16, then 4 decode
+    steps across a page boundary, through Batch + MI355AttnBackend; pools bit-exact, outputs against the fp64 oracle."""
+    m, ops = _mods()
+    ps, lens0, steps = 16, [70, 31, 130], 4
+    n_pages = sum(-(-(l + steps) // ps) for l in lens0) + 8
+    perm = torch.randperm(n_pages, generator=torch.Generator().manual_seed(5)).tolist()
+    kv = m.KVCache(size=n_pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=1, device=DEV,
+                   device_free_list=True)
+    kv.set_free_pages(perm)
+    ctx = max(lens0) + steps + ps
+    pm = m.PageManager(page_size=ps, max_req_num=8, max_context_len=ctx, device=DEV)
+    backend = m.MI355AttnBackend(_runner(m, ps, kv, pm))
+    layer = m.Attention(layer_id=0, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=D ** -0.5)
+    pool = M.RefPagePool(n_pages, ps)
+    pool.free_pages = list(perm)
+    pt = M.RefPageTable(ps, 8, ctx)
+    rk = torch.zeros((n_pages * ps, Hkv, D), dtype=torch.bfloat16)
+    rv = torch.zeros_like(rk)
+    reqs = []
+    for i, l in enumerate(lens0):
+        r = m.Req(i, list(range(l)))
+        r.fill_ids = list(r.origin_input_ids)
+        reqs.append(r)
+    batch = m.Batch(reqs, page_manager=pm, kvcache=kv, device=DEV)
+    batch.prepare_for_prefill()
+    meta = M.prepare_for_prefill_ref([M.RefReq(fill_ids=list(range(l))) for l in lens0], pool, pt)
+    for step in range(-1, steps):
+        if step >= 0:
+            nxt = [1000 + step + i for i in range(len(lens0))]
+            batch.output_ids = torch.tensor(nxt, dtype=torch.int64, device=DEV)
+            batch.prepare_for_decode()
+            meta = M.prepare_for_decode_ref(meta, nxt, pool, pt)
+        for f in ("seq_lens", "positions", "out_cache_loc", "page_table_ids"):
+            assert np.array_equal(getattr(batch, f).cpu().numpy(), getattr(meta, f)), (step, f)
+        T = int(meta.input_ids.shape[0])
+        qkv = synth((T, (Hq + 2 * Hkv) * D), 70 + step, amp=2.0, dtype=torch.bfloat16)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        A.write_kv_ref(rk, rv, torch.from_numpy(meta.out_cache_loc), k.view(-1, Hkv, D), v.view(-1, Hkv, D))
+        ref = A.paged_attn_f64(q.reshape(T, Hq, D), rk, rv, torch.from_numpy(pt.table), torch.from_numpy(meta.page_table_ids),
+                               torch.from_numpy(meta.seq_lens), torch.from_numpy(meta.prefix_lens) if step < 0 else None,
+                               ps).reshape(T, Hq * D).float().numpy()
+        dq, dk, dv = qkv.to(DEV).split([Hq * D, Hkv * D, Hkv * D], dim=-1)      # strided views of the packed projection
+        backend.init_forward_metadata(batch)
+        o = backend.forward(dq, dk, dv, layer, batch)
+        torch.cuda.synchronize()
+        assert o.shape == (T, Hq * D) and o.dtype == torch.bfloat16
+        kp, vp = kv.get_kv_cache(0)
+        assert torch.equal(kp.cpu(), rk) and torch.equal(vp.cpu(), rv), step
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"step {step}")
+
+
+# ------------------------------------------------------------------------------------------------
 # cfg5
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B", [1, 8])

@@ -363,3 +363,15 @@ def test_native_radix_library_exports_its_header():
     lib.m355r_version.restype = ctypes.c_int
     assert lib.m355r_version() == 1
 
+
+
+def test_group_sizes_run_in_the_next_built_one():
+    """Backend: query heads per kv head outside {1, 2, 4, 8} are padded up (tests/test_gpu_configs.py checks the results);
+    more than 8, or a head count that is no multiple of the kv heads, is refused."""
+    from mi355_attn._lib import MI355AttnError
+    from mi355_attn.backend import _group_pad
+    assert [_group_pad(h, 8) for h in (8, 16, 24, 32, 40, 56, 64)] == [1, 2, 4, 4, 8, 8, 8]
+    with pytest.raises(MI355AttnError):
+        _group_pad(72, 8)
+    with pytest.raises(MI355AttnError):
+        _group_pad(30, 8)
