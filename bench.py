@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling passes)")
     ap.add_argument("--fused-probe", action="store_true", help="internal: child of an N>1 run, see fused_probe()")
+    ap.add_argument("--one-batch-graph-child", action="store_true", help="internal: child of an N>1 run, see one_batch_graph_tp()")
     ap.add_argument("--heads", type=str, default="", help="experiment: Hq,Hkv,D per GPU instead of the 1B shape")
     ap.add_argument("--copies", type=int, default=0, help="experiment: batch = 64 * copies")
     ap.add_argument("--fixed-len", type=int, default=0, help="experiment: every request has this length (with --batch)")
@@ -83,6 +84,8 @@ def main():
 
     if args.fused_probe:
         sys.exit(fused_probe_child())
+    if args.one_batch_graph_child:
+        sys.exit(one_batch_graph_child())
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,6 +231,10 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
     if tp > 1:
         note(rank, f"probe {'ok' if fused_ok else 'FAILED'}; bench_one_batch")
     out["bench_one_batch_llama3_8b"] = guarded(one_batch, dev, tp, rank, rehearse, fused_ok)
+    if tp > 1:
+        note(rank, "bench_one_batch with the decode step captured as a graph (child processes)")
+        out["bench_one_batch_llama3_8b"]["graph_rccl"] = one_batch_graph_tp(dev, tp, rank) if isinstance(
+            out["bench_one_batch_llama3_8b"], dict) else None
     note(rank, "bench_one_batch done")
     if tp > 1:
         out.update(guarded(collective_legs, dev, tp, rank, rehearse, fence, fused_ok))
@@ -243,8 +250,7 @@ def fused_probe(dev, tp) -> bool:
     `except` catches.  So its first run across these GPUs happens in CHILD processes (one per rank, their own gloo group
     on the next port, same devices): if a child faults, gives up waiting or disagrees with the plain sum, the ranks of
     this run skip the fused legs and the bench line survives."""
-    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}   # (the children keep their own store)
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 23)
+    env = child_env(23)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused-probe"], env=env, capture_output=True, text=True,
                            timeout=240)
@@ -334,8 +340,8 @@ def one_batch(dev, tp, rank, rehearse, fused_ok=False):
     B=64, input 1024, 32 output tokens; tok/s = B * decode steps / sum(decode step time).  TP=N under torch.distributed."""
     import bench_one_batch as ob
     from harness.llama_shell import SHAPES, HarnessRunner
-    model = "tiny" if rehearse else "llama-3-8b"          # (a gloo rehearsal cannot all-reduce 8B-size activations in minutes)
-    bs, il, ol = (4, 64, 8) if rehearse else (64, 1024, 32)
+    c = ONE_BATCH_REHEARSAL if rehearse else ONE_BATCH_TP  # (a gloo rehearsal cannot all-reduce 8B-size activations in minutes)
+    model, bs, il, ol = c["model"], c["bs"], c["il"], c["ol"]
     shape = SHAPES[model]
     runner = HarnessRunner(shape, PAGE_SIZE, max_total_tokens=bs * (il + ol + 2 * PAGE_SIZE) + 64 * PAGE_SIZE, max_reqs=bs,
                            context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=tp, device=dev, fused_row_parallel=fused_ok)
@@ -357,6 +363,67 @@ def one_batch(dev, tp, rank, rehearse, fused_ok=False):
         res["fused_oproj_wait_gave_up"] = bool(int(fused.error.item()))
         fused.close()
     return res
+
+
+ONE_BATCH_TP = dict(model="llama-3-8b", bs=64, il=1024, ol=32)
+ONE_BATCH_REHEARSAL = dict(model="tiny", bs=4, il=64, ol=8)
+
+
+def child_env(port_offset: int) -> dict:
+    """Environment of a child rank: this rank's, on its own rendezvous port, without the launcher's store settings."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
+    return env
+
+
+def one_batch_graph_tp(dev, tp, rank):
+    """bench_one_batch at TP = N with the decode step - every layer, its RCCL all-reduces, sampling - replayed from a HIP
+    graph (eager decode at TP = 8 is bound by the host's launch rate, not by the GPUs).  Capturing collectives is the one
+    thing here a one-GPU box cannot rehearse, so it runs in child processes (one per rank, own process group): a capture
+    that raises, hangs or dies costs this field, not the bench line."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-batch-graph-child"], env=child_env(29),
+                           capture_output=True, text=True, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("ONE_BATCH_CHILD ")]
+        res = json.loads(lines[-1][len("ONE_BATCH_CHILD "):]) if (r.returncode == 0 and lines) else None
+        err = None if r.returncode == 0 else (r.stderr.strip().splitlines() or ["?"])[-1][:300]
+    except Exception as e:      # noqa: BLE001  (timeout, spawn failure)
+        res, err = None, repr(e)[:300]
+    ok = torch.tensor([1 if err is None else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if not int(ok.item()):
+        return {"error": "a child rank failed" + (f": {err}" if err else "")}
+    return res if res is not None else {"note": "measured by rank 0's child"}
+
+
+def one_batch_graph_child() -> int:
+    import datetime
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    rehearse = os.environ.get("M355_BENCH_REHEARSE") == "1"
+    local_rank = 0 if rehearse else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if rehearse:                # (gloo cannot be captured: the rehearsal checks the plumbing with an eager loop)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+    else:
+        dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=300))
+    import bench_one_batch as ob
+    from harness.llama_shell import SHAPES, HarnessRunner
+    c = ONE_BATCH_REHEARSAL if rehearse else ONE_BATCH_TP
+    shape = SHAPES[c["model"]]
+    bs, il, ol = c["bs"], c["il"], c["ol"]
+    runner = HarnessRunner(shape, PAGE_SIZE, max_total_tokens=bs * (il + ol + 2 * PAGE_SIZE) + 64 * PAGE_SIZE, max_reqs=bs,
+                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=world, device=dev, fused_row_parallel=False)
+    r = ob.latency_test(runner, ob.BenchArgs(graph=not rehearse, model=c["model"]), bs, il, ol, lambda *a, **k: None, world)
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0:
+        print("ONE_BATCH_CHILD " + json.dumps({
+            "decode_graph": bool(r["decode_graph"]), "prefill_tok_per_s": round(r["prefill_throughput"], 1),
+            "prefill_latency_ms": round(r["prefill_latency"] * 1e3, 2), "decode_tok_per_s": round(r["decode_throughput"], 1),
+            "median_decode_step_ms": round(r["median_decode_latency"] * 1e3, 3)}), flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def collective_legs(dev, tp, rank, rehearse, fence, fused_ok=False):
