@@ -233,8 +233,8 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
     out["bench_one_batch_llama3_8b"] = guarded(one_batch, dev, tp, rank, rehearse, fused_ok)
     if tp > 1:
         note(rank, "bench_one_batch with the decode step captured as a graph (child processes)")
-        out["bench_one_batch_llama3_8b"]["graph_rccl"] = one_batch_graph_tp(dev, tp, rank) if isinstance(
-            out["bench_one_batch_llama3_8b"], dict) else None
+        if isinstance(out["bench_one_batch_llama3_8b"], dict):
+            out["bench_one_batch_llama3_8b"].update(one_batch_graph_tp(dev, tp, rank, fused_ok))
     note(rank, "bench_one_batch done")
     if tp > 1:
         out.update(guarded(collective_legs, dev, tp, rank, rehearse, fence, fused_ok))
@@ -376,34 +376,44 @@ def child_env(port_offset: int) -> dict:
     return env
 
 
-def one_batch_graph_tp(dev, tp, rank):
-    """bench_one_batch at TP = N with the decode step - every layer, its RCCL all-reduces, sampling - replayed from a HIP
-    graph (eager decode at TP = 8 is bound by the host's launch rate, not by the GPUs).  Capturing collectives is the one
-    thing here a one-GPU box cannot rehearse, so it runs in child processes (one per rank, own process group): a capture
-    that raises, hangs or dies costs this field, not the bench line."""
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-batch-graph-child"], env=child_env(29),
-                           capture_output=True, text=True, timeout=900)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("ONE_BATCH_CHILD ")]
-        res = json.loads(lines[-1][len("ONE_BATCH_CHILD "):]) if (r.returncode == 0 and lines) else None
-        err = None if r.returncode == 0 else (r.stderr.strip().splitlines() or ["?"])[-1][:300]
-    except Exception as e:      # noqa: BLE001  (timeout, spawn failure)
-        res, err = None, repr(e)[:300]
-    ok = torch.tensor([1 if err is None else 0], device=dev, dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if not int(ok.item()):
-        return {"error": "a child rank failed" + (f": {err}" if err else "")}
-    return res if res is not None else {"note": "measured by rank 0's child"}
+def one_batch_graph_tp(dev, tp, rank, fused_ok):
+    """bench_one_batch at TP = N with the decode step - every layer, its all-reduces, sampling - replayed from a HIP graph
+    (eager decode at TP = 8 is bound by the host's launch rate, not by the GPUs): `graph_rccl` with RCCL all-reduces captured,
+    `graph_fused_oproj` with the one-launch GEMM + reduce where it applies (T <= 64, K <= 2048 per rank).  Capturing
+    collectives is the one thing here a one-GPU box cannot rehearse, so each leg runs in child processes (one per rank, own
+    process group): a capture that raises, hangs or dies costs that field, not the bench line."""
+    out = {}
+    for name, fused, port in (("graph_rccl", False, 29), ("graph_fused_oproj", True, 31)):
+        if fused and not fused_ok:
+            continue
+        try:
+            env = child_env(port)
+            env["M355_CHILD_FUSED"] = "1" if fused else "0"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-batch-graph-child"], env=env,
+                               capture_output=True, text=True, timeout=900)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("ONE_BATCH_CHILD ")]
+            res = json.loads(lines[-1][len("ONE_BATCH_CHILD "):]) if (r.returncode == 0 and lines) else None
+            err = None if r.returncode == 0 else (r.stderr.strip().splitlines() or ["?"])[-1][:300]
+        except Exception as e:      # noqa: BLE001  (timeout, spawn failure)
+            res, err = None, repr(e)[:300]
+        ok = torch.tensor([1 if err is None else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            out[name] = {"error": "a child rank failed" + (f": {err}" if err else "")}
+        else:
+            out[name] = res if res is not None else {"note": "measured by rank 0's child"}
+    return out
 
 
 def one_batch_graph_child() -> int:
     import datetime
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rehearse = os.environ.get("M355_BENCH_REHEARSE") == "1"
+    fused = os.environ.get("M355_CHILD_FUSED") == "1"
     local_rank = 0 if rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if rehearse:                # (gloo cannot be captured: the rehearsal checks the plumbing with an eager loop)
+    if rehearse:
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
     else:
         dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=300))
@@ -413,17 +423,23 @@ def one_batch_graph_child() -> int:
     shape = SHAPES[c["model"]]
     bs, il, ol = c["bs"], c["il"], c["ol"]
     runner = HarnessRunner(shape, PAGE_SIZE, max_total_tokens=bs * (il + ol + 2 * PAGE_SIZE) + 64 * PAGE_SIZE, max_reqs=bs,
-                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=world, device=dev, fused_row_parallel=False)
-    r = ob.latency_test(runner, ob.BenchArgs(graph=not rehearse, model=c["model"]), bs, il, ol, lambda *a, **k: None, world)
+                           context_len=il + ol + PAGE_SIZE, tp_rank=rank, tp_size=world, device=dev, fused_row_parallel=fused)
+    # (a gloo all-reduce cannot be captured: the rehearsal runs the RCCL leg as an eager loop, plumbing only; its tiny
+    # model's row-parallel layers all take the fused launch, so the fused leg IS captured there)
+    graph = fused or not rehearse
+    r = ob.latency_test(runner, ob.BenchArgs(graph=graph, model=c["model"]), bs, il, ol, lambda *a, **k: None, world)
     torch.cuda.synchronize()
+    gave_up = bool(int(runner.model.fused.error.item())) if runner.model.fused is not None else False
     dist.barrier()
     if rank == 0:
         print("ONE_BATCH_CHILD " + json.dumps({
             "decode_graph": bool(r["decode_graph"]), "prefill_tok_per_s": round(r["prefill_throughput"], 1),
             "prefill_latency_ms": round(r["prefill_latency"] * 1e3, 2), "decode_tok_per_s": round(r["decode_throughput"], 1),
-            "median_decode_step_ms": round(r["median_decode_latency"] * 1e3, 3)}), flush=True)
+            "median_decode_step_ms": round(r["median_decode_latency"] * 1e3, 3), "fused_oproj_wait_gave_up": gave_up}), flush=True)
+    if runner.model.fused is not None:
+        runner.model.fused.close()
     dist.destroy_process_group()
-    return 0
+    return 0 if not gave_up else 1
 
 
 def collective_legs(dev, tp, rank, rehearse, fence, fused_ok=False):

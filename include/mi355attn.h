@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define M355_VERSION 210 /* 0.2.1 */
+#define M355_VERSION 211 /* 0.2.11: m355_oproj_allreduce takes an epoch_state */
 
 enum {
     M355_OK = 0,

@@ -17,7 +17,7 @@
  * Set-up (once): each rank allocates one receive buffer and one flag array with m355_comm_alloc (uncached device
  * memory, so data written by a peer is never served from a stale cache line), exports them (m355_comm_export, a 64-byte
  * handle that travels by any host channel), opens the peers' (m355_comm_open).  Per call nothing is allocated and
- * nothing synchronises; `epoch` must grow by one per call on every rank (flags are never cleared; the receive buffer
+ * nothing synchronises; the epoch must grow by one per call on every rank (flags are never cleared; the receive buffer
  * has two halves used by even / odd epochs, which is enough because a rank cannot begin call e+2 before every peer has
  * finished reading call e).  Waits are bounded: a peer that never arrives raises *error (device int32) instead of
  * hanging the GPU.
@@ -65,9 +65,13 @@ int64_t m355_oproj_flag_bytes(int32_t world, int32_t T_cap, int32_t N);
 /* out = sum over ranks of x_r . w_r^T, replacing F.linear + dist.all_reduce (layers/linear.py:228-232).
  * `ranks` (HOST memory) holds n_ranks entries: 1 in production (this process's rank); n_ranks == world runs every rank
  * of a world whose buffers all live on THIS device in one launch (how the single-GPU parity test drives it).
- * T <= T_cap rows; N % 64 == 0; K % 32 == 0; bf16 or f16.  error: device int32 raised to 1 when a wait gave up, or NULL. */
+ * T <= T_cap rows; N % 64 == 0; K % 32 == 0; bf16 or f16.  error: device int32 raised to 1 when a wait gave up, or NULL.
+ * The call's epoch is `epoch` (counted by the host: 1, 2, 3, ...) when epoch_state is NULL.  Otherwise epoch_state is
+ * device memory of m355_oproj_flag_bytes(world, T_cap, N) bytes, zeroed once at set-up, where the launch keeps a call
+ * count per (rank, tile) and advances it itself: the SAME launch (same arguments) can then be replayed from a captured HIP
+ * graph; `epoch` is ignored.  Every rank must use the same form, and with it the same sequence of calls. */
 int m355_oproj_allreduce(const M355OprojRank *ranks, int32_t n_ranks, int32_t world, int32_t T, int32_t N, int32_t K,
-                         int32_t T_cap, uint32_t epoch, int32_t *error, int32_t dtype, void *stream);
+                         int32_t T_cap, uint32_t epoch, uint32_t *epoch_state, int32_t *error, int32_t dtype, void *stream);
 
 #ifdef __cplusplus
 }

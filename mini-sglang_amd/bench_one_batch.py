@@ -52,6 +52,7 @@ class BenchArgs:                                    # bench_one_batch.py:72-84
     model: str = "llama-3-8b"
     page_size: int = 16
     graph: bool = False                             # decode steps replayed from one captured HIP graph (GraphedDecode)
+    fused_row_parallel: bool = False                # TP: o_proj / down_proj + all-reduce as one launch where it applies
 
     @staticmethod
     def add_cli_args(p: argparse.ArgumentParser):
@@ -64,7 +65,9 @@ class BenchArgs:                                    # bench_one_batch.py:72-84
         p.add_argument("--cut-len", type=int, default=BenchArgs.cut_len)
         p.add_argument("--model", type=str, default=BenchArgs.model, choices=sorted(SHAPES))
         p.add_argument("--page-size", type=int, default=BenchArgs.page_size)
-        p.add_argument("--graph", action="store_true", help="decode through one captured HIP graph per run (single GPU)")
+        p.add_argument("--graph", action="store_true", help="decode through one captured HIP graph per run")
+        p.add_argument("--fused-row-parallel", action="store_true",
+                       help="under TP: row-parallel GEMM + all-reduce in one launch (m355_oproj_allreduce) for decode-size inputs")
 
 
 def synth_prompts(batch_size: int, input_len: int, vocab: int, seed: int = 0) -> List[List[int]]:
@@ -299,7 +302,8 @@ def main():
     shape = SHAPES[ba.model]
     max_bs, max_len = max(ba.batch_size), max(ba.input_len) + max(ba.output_len) + ba.page_size
     runner = HarnessRunner(shape, ba.page_size, max_total_tokens=max_bs * (max_len + ba.page_size) + 64 * ba.page_size,
-                           max_reqs=max_bs, context_len=max_len, tp_rank=rank, tp_size=world, device=dev)
+                           max_reqs=max_bs, context_len=max_len, tp_rank=rank, tp_size=world, device=dev,
+                           fused_row_parallel=ba.fused_row_parallel)
     if ba.correctness_test:
         err, ref, same = correctness_test(runner, ba, rank_print)
         ok = err <= 0.05 * max(ref, 1.0)

@@ -23,6 +23,7 @@ struct OprojParams {
     M355OprojRank r[M355_MAX_RANKS];
     int32_t world, T, N, K, T_cap;
     uint32_t epoch;
+    uint32_t* epoch_state;                   // device [world][tiles_cap] calls made per (rank, tile), or null: `epoch` counts on the host
     int32_t* error;
 };
 
@@ -47,6 +48,14 @@ template <bool F16>
 __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams p) {
     __shared__ __attribute__((aligned(16))) float red[4][16][68];
     const M355OprojRank& R = p.r[blockIdx.z];
+    // the call's epoch: the host's count, or - so that ONE captured launch can be replayed - a count per (rank, tile) in
+    // device memory that the tile's own workgroup reads here and writes back at its end: no other workgroup of any launch
+    // on this device touches the word, every rank makes the same calls, so the counts agree across ranks tile by tile
+    const int tiles_x = p.N / 64;
+    const int tile = blockIdx.y * tiles_x + blockIdx.x;
+    const int tiles_cap = ((p.T_cap + 15) / 16) * tiles_x;
+    uint32_t* const own_epoch = p.epoch_state ? p.epoch_state + (int64_t)R.rank * tiles_cap + tile : nullptr;
+    const uint32_t epoch = own_epoch ? *own_epoch + 1u : p.epoch;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 16;
@@ -91,10 +100,7 @@ __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams 
     // ---- push: thread (half, idx) holds row idx / 8, columns 8 (idx % 8) .. + 8; the two halves serve alternate peers
     const int half = threadIdx.x >> 7, idx = threadIdx.x & 127;
     const int row = idx >> 3, c8 = (idx & 7) * 8;
-    const int tiles_x = p.N / 64;
-    const int tile = blockIdx.y * tiles_x + blockIdx.x;
-    const int tiles_cap = ((p.T_cap + 15) / 16) * tiles_x;
-    const int parity = p.epoch & 1u;
+    const int parity = epoch & 1u;
     const bool live = row0 + row < p.T;
     {
         float v[8];
@@ -109,13 +115,13 @@ __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece of the tile has been acknowledged by its destination
     __syncthreads();                                     // ... for all 256 threads: only then the flags go out
     if ((int)threadIdx.x < p.world)
-        __hip_atomic_store(R.flags[threadIdx.x] + (int64_t)R.rank * tiles_cap + tile, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(R.flags[threadIdx.x] + (int64_t)R.rank * tiles_cap + tile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     // ---- wait for this tile of every rank (bounded), then add the slots in rank order
     if ((int)threadIdx.x < p.world) {
         const uint32_t* f = R.flags[R.rank] + (int64_t)threadIdx.x * tiles_cap + tile;
         int spins = 0;
-        while ((int32_t)(ld_sys(f) - p.epoch) < 0) {
+        while ((int32_t)(ld_sys(f) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(4);
             if (++spins > kOprojPollLimit) {
                 if (p.error) __hip_atomic_store(p.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams 
         const u32x4 o = {pack16<F16>(s[0], s[1]), pack16<F16>(s[2], s[3]), pack16<F16>(s[4], s[5]), pack16<F16>(s[6], s[7])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(R.out) + (int64_t)(row0 + row) * R.out_row_stride + col0 + c8) = o;
     }
+    if (own_epoch && threadIdx.x == 0) *own_epoch = epoch;
 }
 
 }  // namespace m355
@@ -186,11 +193,13 @@ extern "C" int64_t m355_oproj_flag_bytes(int32_t world, int32_t T_cap, int32_t N
 }
 
 extern "C" int m355_oproj_allreduce(const M355OprojRank* ranks, int32_t n_ranks, int32_t world, int32_t T, int32_t N, int32_t K,
-                                    int32_t T_cap, uint32_t epoch, int32_t* error, int32_t dtype, void* stream) {
+                                    int32_t T_cap, uint32_t epoch, uint32_t* epoch_state, int32_t* error, int32_t dtype,
+                                    void* stream) {
     if (T == 0) return M355_OK;
     if (!ranks || n_ranks < 1 || world < 1 || world > M355_MAX_RANKS || n_ranks > world || T < 0 || T > T_cap || N <= 0 || K <= 0)
         return M355_ERR_INVALID_ARG;
     if (n_ranks != 1 && n_ranks != world) return M355_ERR_INVALID_ARG;
+    if ((uintptr_t)epoch_state & 3) return M355_ERR_INVALID_ARG;
     if (N % 64 || K % 32) return M355_ERR_UNSUPPORTED;
     if (dtype != M355_DTYPE_BF16 && dtype != M355_DTYPE_F16) return M355_ERR_UNSUPPORTED;
     if ((int64_t)((T + 15) / 16) * (N / 64) * n_ranks > 65535ll * 16) return M355_ERR_INVALID_ARG;
@@ -207,7 +216,7 @@ extern "C" int m355_oproj_allreduce(const M355OprojRank* ranks, int32_t n_ranks,
             if (!r.recv[q] || !r.flags[q] || ((uintptr_t)r.recv[q] & 15)) return M355_ERR_INVALID_ARG;
         p.r[i] = r;
     }
-    p.world = world; p.T = T; p.N = N; p.K = K; p.T_cap = T_cap; p.epoch = epoch; p.error = error;
+    p.world = world; p.T = T; p.N = N; p.K = K; p.T_cap = T_cap; p.epoch = epoch; p.epoch_state = epoch_state; p.error = error;
     const dim3 grid((unsigned)(N / 64), (unsigned)((T + 15) / 16), (unsigned)n_ranks);
     if (dtype == M355_DTYPE_F16) hipLaunchKernelGGL((oproj_allreduce_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((oproj_allreduce_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);

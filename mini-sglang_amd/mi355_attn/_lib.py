@@ -72,7 +72,7 @@ SIGNATURES = {
     "m355_oproj_recv_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "m355_oproj_flag_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "m355_oproj_allreduce": (c_int32, [POINTER(OprojRank), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32,
-                                       c_void_p, c_int32, c_void_p]),
+                                       c_void_p, c_void_p, c_int32, c_void_p]),
     "m355_rope_kv_store": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                      c_int64, c_int32, c_void_p]),

@@ -100,7 +100,7 @@ class FusedRowParallel:
     the single-GPU parity test, where no second GPU exists."""
 
     def __init__(self, out_features: int, t_cap: int = 256, group: Optional[dist.ProcessGroup] = None,
-                 local_world: int = 0, device=None):
+                 local_world: int = 0, device=None, device_epoch: bool = True):
         from . import _lib
         self._lib, self._L = _lib, _lib.load()
         self.N, self.t_cap, self.epoch = int(out_features), int(t_cap), 0
@@ -117,6 +117,10 @@ class FusedRowParallel:
         self._own: List[int] = []          # allocations of this process
         self._opened: List[int] = []       # peers' allocations opened here
         self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # the calls' epoch lives on the device (a call count per (rank, tile) that the launch advances itself), so a call
+        # has the same arguments every time and a captured decode step can replay it
+        # (device_epoch=False: the host counts, the other form of the C ABI; every rank must use the same one)
+        self.epoch_state = torch.zeros(fb // 4, dtype=torch.int32, device=self.device) if device_epoch else None
         with torch.cuda.device(self.device):
             if self.local:
                 self.recv = [self._alloc(rb) for _ in range(self.world)]
@@ -186,7 +190,9 @@ class FusedRowParallel:
             e.out, e.out_row_stride = oi.data_ptr(), oi.stride(0)
         self.epoch += 1
         self._lib.check(self._L.m355_oproj_allreduce(arr, len(xs), self.world, T, self.N, K, self.t_cap, self.epoch & 0xffffffff,
-                                                     self.error.data_ptr(), self._lib.dtype_code(xs[0].dtype),
+                                                     None if self.epoch_state is None else self.epoch_state.data_ptr(),
+                                                     self.error.data_ptr(),
+                                                     self._lib.dtype_code(xs[0].dtype),
                                                      self._lib.current_stream()), "m355_oproj_allreduce")
         return outs if self.local else outs[0]
 

@@ -76,6 +76,21 @@ def test_tp2_rehearsal_matches_tp1_first_tokens():
     assert len(first(one.stdout)) == 3 and first(one.stdout) == first(two.stdout)
 
 
+def test_tp2_graphed_decode_with_the_fused_epilogue():
+    """Two ranks on this one GPU: the decode step captured as a HIP graph with the row-parallel layers' GEMM + all-reduce
+    as one-launch kernels inside it (m355_oproj_allreduce, epochs kept on the device) generates the tokens of the eager
+    two-rank loop, and passes the three-phase correctness test."""
+    import subprocess
+    script = os.path.join(os.path.dirname(HERE), "mini-sglang_amd", "bench_one_batch.py")
+    args = ["--model", "tiny", "--correctness-test", "--graph", "--fused-row-parallel", "--batch-size", "3", "--input-len", "70",
+            "--output-len", "8", "--cut-len", "32"]
+    env = dict(os.environ, M355_BENCH_REHEARSE="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29519", script] + args, capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode == 0 and "correctness: PASS" in two.stdout, two.stdout[-2000:] + two.stderr[-2000:]
+    assert "graphed decode tokens identical to the eager loop: True" in two.stdout, two.stdout[-2000:]
+
+
 @pytest.mark.parametrize("model,ps", [("tiny", 16), ("tiny128", 4)])
 def test_graphed_decode_equals_the_eager_loop(model, ps):
     """One decode step captured as a HIP graph (device free list, in-place metadata, fixed plan layout) and replayed

@@ -48,6 +48,56 @@ def test_fused_oproj_matches_linear_plus_allreduce(world, T, N, K, dtype):
         f.close()
 
 
+@pytest.mark.parametrize("device_epoch", [True, False], ids=["epoch_on_device", "epoch_from_host"])
+def test_fused_oproj_both_epoch_forms(device_epoch):
+    """The epoch a call carries comes from the host's count or from the device word that each launch advances itself:
+    five calls each way (both buffer halves, several times) give the same results."""
+    from mi355_attn.tp import FusedRowParallel
+    world, T, N, K = 4, 48, 1024, 512
+    f = FusedRowParallel(N, t_cap=64, local_world=world, device="cuda:0", device_epoch=device_epoch)
+    try:
+        for call in range(5):
+            xs, ws, want = _case(world, T, N, K, torch.bfloat16, seed=10 + call)
+            outs = f(xs, ws)
+            torch.cuda.synchronize()
+            f.check()
+            assert all(torch.equal(o, outs[0]) for o in outs)
+            torch.testing.assert_close(outs[0].float(), want, atol=2e-2, rtol=2e-2)
+        if device_epoch:
+            assert sorted(set(f.epoch_state.tolist())) == [0, 5]     # tiles of the 3 row blocks in use: five calls each
+    finally:
+        f.close()
+
+
+def test_fused_oproj_replays_from_a_graph():
+    """One captured launch, replayed with new inputs in the same buffers: the device-side epoch is what makes the
+    arguments of every replay identical (bench_one_batch's captured decode step under TP uses it this way)."""
+    from mi355_attn.tp import FusedRowParallel
+    world, T, N, K = 2, 64, 2048, 1024
+    f = FusedRowParallel(N, t_cap=64, local_world=world, device="cuda:0")
+    try:
+        xs, ws, want = _case(world, T, N, K, torch.bfloat16, seed=20)
+        outs = [torch.empty((T, N), dtype=torch.bfloat16, device="cuda") for _ in range(world)]
+        f(xs, ws, out=outs)                                  # eager once (epoch 1)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            f(xs, ws, out=outs)
+        for rep in range(4):
+            nx, _, _ = _case(world, T, N, K, torch.bfloat16, seed=30 + rep)
+            for x, n in zip(xs, nx):
+                x.copy_(n)
+            want = sum(torch.nn.functional.linear(x.float(), w.float()).to(torch.bfloat16).float() for x, w in zip(xs, ws))
+            g.replay()
+            torch.cuda.synchronize()
+            f.check()
+            assert torch.equal(outs[0], outs[1])
+            torch.testing.assert_close(outs[0].float(), want, atol=2e-2, rtol=2e-2)
+        assert sorted(set(f.epoch_state.tolist())) == [5]
+    finally:
+        f.close()
+
+
 def test_fused_oproj_refuses_bad_shapes():
     from mi355_attn import _lib
     from mi355_attn.tp import FusedRowParallel
