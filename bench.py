@@ -253,7 +253,7 @@ def fused_probe(dev, tp) -> bool:
     env = child_env(23)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused-probe"], env=env, capture_output=True, text=True,
-                           timeout=240)
+                           timeout=150)
         ok = r.returncode == 0 and "FUSED_PROBE_OK" in r.stdout
     except Exception:           # noqa: BLE001  (timeout, spawn failure)
         ok = False
@@ -390,7 +390,7 @@ def one_batch_graph_tp(dev, tp, rank, fused_ok):
             env = child_env(port)
             env["M355_CHILD_FUSED"] = "1" if fused else "0"
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-batch-graph-child"], env=env,
-                               capture_output=True, text=True, timeout=900)
+                               capture_output=True, text=True, timeout=300)
             lines = [l for l in r.stdout.splitlines() if l.startswith("ONE_BATCH_CHILD ")]
             res = json.loads(lines[-1][len("ONE_BATCH_CHILD "):]) if (r.returncode == 0 and lines) else None
             err = None if r.returncode == 0 else (r.stderr.strip().splitlines() or ["?"])[-1][:300]
