@@ -375,6 +375,56 @@ def test_prefill_attn_ragged_prefix(Hq, Hkv, D, ps):
     np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
 
 
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 64), (8, 1, 128)])
+def test_degenerate_batches(Hq, Hkv, D):
+    """Requests with nothing to do next to ordinary ones, and empty batches: an extend of zero tokens (its prefix covers the
+    whole sequence) and a decode request of length zero add no rows / leave their output row alone, and the others come
+    out as if the degenerate ones were not there; B == 0 and T == 0 calls return at once."""
+    m, ops = _mods()
+    ps = 16
+    # ---- prefill: extends of 0, 7, 0, 40, 0 tokens
+    seq = [32, 39, 16, 104, 0]
+    pre = [32, 32, 16, 64, 0]
+    B = len(seq)
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, [max(s, 1) for s in seq], seed=77)
+    ext = [s_ - p_ for s_, p_ in zip(seq, pre)]
+    T = sum(ext)
+    g = torch.Generator().manual_seed(3)
+    q = (torch.randn((T, Hq * D), generator=g) * 2).to(torch.bfloat16)
+    live = [b for b in range(B) if ext[b] > 0]
+    ref = A.paged_attn_f64(q.view(T, Hq, D), kp, vp, torch.from_numpy(table), torch.from_numpy(rows[live]),
+                           torch.tensor([seq[b] for b in live]), torch.tensor([pre[b] for b in live]), ps).reshape(T, Hq * D)
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(ext)]), dtype=torch.int32, device=DEV)
+    dk, dv, dt, dr = kp.to(DEV), vp.to(DEV), torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV)
+    o = ops.prefill_attn(q.to(DEV), dk, dv, dt, dr, torch.tensor(seq, device=DEV), torch.tensor(pre, device=DEV), cu, ps, Hq,
+                         max(ext), max(seq))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref.float().numpy(), rtol=BF16_RTOL, atol=BF16_ATOL)
+    # ---- decode: lengths 0, 1, 17, 0, 300 (planned, with both plan capacities; the self-contained call)
+    lens = [0, 1, 17, 0, 300]
+    table, rows, kp, vp = _random_paged_case(B, Hq, Hkv, D, ps, [max(l, 1) for l in lens], seed=78)
+    dk, dv, dt, dr = kp.to(DEV), vp.to(DEV), torch.from_numpy(table).to(DEV), torch.from_numpy(rows).to(DEV)
+    qd = (torch.randn((B, Hq * D), generator=g) * 2).to(torch.bfloat16)
+    livd = [b for b in range(B) if lens[b] > 0]
+    refd = A.paged_attn_f64(qd.view(B, Hq, D)[livd], kp, vp, torch.from_numpy(table), torch.from_numpy(rows[livd]),
+                            torch.tensor([lens[b] for b in livd]), None, ps).reshape(len(livd), Hq * D).float().numpy()
+    dl = torch.tensor(lens, device=DEV)
+    for cap in (sum(lens), 5000):
+        plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, cap)
+        out = torch.full((B, Hq * D), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.decode_attn_planned(qd.to(DEV), dk, dv, plan, Hq, out=out)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out[livd].float().cpu().numpy(), refd, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"cap {cap}")
+        assert torch.isfinite(out.float()).all()
+    o2 = ops.decode_attn(qd.to(DEV), dk, dv, dt, dr, dl, ps, Hq, max(lens))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o2[livd].float().cpu().numpy(), refd, rtol=BF16_RTOL, atol=BF16_ATOL)
+    # ---- nothing at all
+    e64, e32 = torch.empty(0, dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert ops.prefill_attn(q[:0].to(DEV), dk, dv, dt, e64, e64, e64, e32, ps, Hq, 0, 0).shape == (0, Hq * D)
+    assert ops.decode_attn(qd[:0].to(DEV), dk, dv, dt, e64, e64, ps, Hq, 16).shape == (0, Hq * D)
+
+
 def _gpu_prefill_reference(q, kp, vp, table, rows, seq, pre, ps, Hq):
     """torch fp32 on the GPU, one request at a time: row j of the extend sees cached tokens 0 .. pre + j."""
     Hkv, D = kp.shape[1], kp.shape[2]
