@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams 
     const int tile = blockIdx.y * tiles_x + blockIdx.x;
     const int tiles_cap = ((p.T_cap + 15) / 16) * tiles_x;
     uint32_t* const own_epoch = p.epoch_state ? p.epoch_state + (int64_t)R.rank * tiles_cap + tile : nullptr;
-    const uint32_t epoch = own_epoch ? *own_epoch + 1u : p.epoch;
+    // (agent-scope accesses: the word was written by a workgroup of the previous launch, possibly on another XCD; a stale
+    // count here would make every rank read the previous call's tiles - all ranks equal, all wrong)
+    const uint32_t epoch = own_epoch ? __hip_atomic_load(own_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : p.epoch;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 16;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams 
         const u32x4 o = {pack16<F16>(s[0], s[1]), pack16<F16>(s[2], s[3]), pack16<F16>(s[4], s[5]), pack16<F16>(s[6], s[7])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(R.out) + (int64_t)(row0 + row) * R.out_row_stride + col0 + c8) = o;
     }
-    if (own_epoch && threadIdx.x == 0) *own_epoch = epoch;
+    if (own_epoch && threadIdx.x == 0) __hip_atomic_store(own_epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace m355
