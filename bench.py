@@ -99,6 +99,7 @@ def main():
     dev = f"cuda:{local_rank}"
     if world > 1:
         if rehearse:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo must not go looking up the host name (it may not resolve)
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))     # RCCL over xGMI
@@ -268,6 +269,7 @@ def fused_probe_child() -> int:
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     import datetime
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo must not go looking up the host name (it may not resolve)
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))
     from mi355_attn.tp import FusedRowParallel
     hidden, T = 4096, 64
@@ -414,6 +416,7 @@ def one_batch_graph_child() -> int:
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if rehearse:
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo must not go looking up the host name (it may not resolve)
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
     else:
         dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=300))

@@ -229,6 +229,12 @@ def correctness_test(runner, bench_args: BenchArgs, rank_print):
         rank_print(f"graphed decode tokens identical to the eager loop: {gsame}")
         if not gsame:
             same = 0.0
+    fused = getattr(runner.model, "fused", None)
+    if fused is not None:
+        # (two ranks rehearsing on ONE GPU depend on the device running both processes' kernels side by side; when it does not,
+        # a bounded wait gives up after a second and the tokens that follow mean nothing)
+        torch.cuda.synchronize()
+        rank_print(f"fused row-parallel waits gave up: {bool(int(fused.error.item()))}")
     return err, ref, same
 
 
@@ -295,6 +301,7 @@ def main():
     dev = f"cuda:{local}"
     if world > 1:
         if rehearse:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo must not go looking up the host name (it may not resolve)
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))

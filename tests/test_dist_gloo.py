@@ -29,6 +29,7 @@ def _worker(rank: int, world: int, port: int, results):
                 sys.path.insert(0, p)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         torch.set_num_threads(2)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo must not go looking up the host name (it may not resolve)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import mi355_attn as m
         from mi355_attn.batch import plan_decode, plan_prefill
