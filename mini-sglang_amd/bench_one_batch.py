@@ -234,7 +234,10 @@ def correctness_test(runner, bench_args: BenchArgs, rank_print):
         # (two ranks rehearsing on ONE GPU depend on the device running both processes' kernels side by side; when it does not,
         # a bounded wait gives up after a second and the tokens that follow mean nothing)
         torch.cuda.synchronize()
-        rank_print(f"fused row-parallel waits gave up: {bool(int(fused.error.item()))}")
+        gave_up = fused.error.clone()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(gave_up, op=dist.ReduceOp.MAX)             # on ANY rank
+        rank_print(f"fused row-parallel waits gave up: {bool(int(gave_up.item()))}")
     return err, ref, same
 
 
