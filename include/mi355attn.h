@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define M355_VERSION 211 /* 0.2.11: m355_oproj_allreduce takes an epoch_state */
+#define M355_VERSION 212 /* 0.2.12: m355_oproj_allreduce takes an epoch_state; m355_comm_zero */
 
 enum {
     M355_OK = 0,

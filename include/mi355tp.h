@@ -50,9 +50,14 @@ typedef struct M355OprojRank {
     int32_t reserved;
 } M355OprojRank;
 
-/* Uncached, zero-filled device memory on the current device / its release.  Set-up time only. */
+/* Uncached, zero-filled device memory on the current device / its release.  Set-up time only.
+ * Keep these allocations for the life of the process (mi355_attn.tp pools them): on ROCm 7.2 / gfx950 a normal allocation
+ * that later lands on the address range of a FREED uncached one was seen read through stale 4 KiB translations (whole
+ * pages of a fresh tensor holding old data) - m355_comm_free is for process tear-down. */
 int m355_comm_alloc(int64_t bytes, void **ptr);
 int m355_comm_free(void *ptr);
+/* Zero an allocation again (set-up time; synchronises): for a caller that keeps buffers and re-uses them. */
+int m355_comm_zero(void *ptr, int64_t bytes);
 /* Inter-process handle (64 bytes, host memory) of a m355_comm_alloc allocation; open / close it in another process. */
 int m355_comm_export(void *ptr, void *handle64);
 int m355_comm_open(const void *handle64, void **ptr);

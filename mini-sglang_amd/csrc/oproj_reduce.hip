@@ -3,7 +3,7 @@
 // every rank in rank order.  Replaces F.linear + dist.all_reduce (reference layers/linear.py:228-232) at decode sizes,
 // where the collective is latency-bound: no second kernel, no ring steps, every link of the GPU busy at once.
 //
-//   grid  (N / 64, ceil(T / 16), ranks in this launch), 256 threads = 4 waves
+//   grid  (N / 64, ceil(T / 16), ranks in this launch), 320 threads = 4 working waves + 1 that fetches the call's epoch
 //   GEMM  the workgroup's 4 waves split K; each runs  acc[j] += W_j (16 x 32) . X^T (32 x 16)  with
 //         v_mfma_f32_16x16x32 - W as the A operand, so a lane ends up with 4 CONSECUTIVE output columns of one token -
 //         and the four partial tiles are added through LDS in a fixed order
@@ -45,26 +45,36 @@ __device__ __forceinline__ u32x4 ld16_sys(const void* p) {
 }
 
 template <bool F16>
-__global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams p) {
+__global__ __launch_bounds__(320) void oproj_allreduce_kernel(const OprojParams p) {
     __shared__ __attribute__((aligned(16))) float red[4][16][68];
+    __shared__ uint32_t epoch_s;
     const M355OprojRank& R = p.r[blockIdx.z];
     // the call's epoch: the host's count, or - so that ONE captured launch can be replayed - a count per (rank, tile) in
-    // device memory that the tile's own workgroup reads here and writes back at its end: no other workgroup of any launch
+    // device memory that the tile's own workgroup reads and advances (wave 4, below): no other workgroup of any launch
     // on this device touches the word, every rank makes the same calls, so the counts agree across ranks tile by tile
     const int tiles_x = p.N / 64;
     const int tile = blockIdx.y * tiles_x + blockIdx.x;
     const int tiles_cap = ((p.T_cap + 15) / 16) * tiles_x;
     uint32_t* const own_epoch = p.epoch_state ? p.epoch_state + (int64_t)R.rank * tiles_cap + tile : nullptr;
-    // (agent-scope accesses: the word was written by a workgroup of the previous launch, possibly on another XCD; a stale
-    // count here would make every rank read the previous call's tiles - all ranks equal, all wrong)
-    const uint32_t epoch = own_epoch ? __hip_atomic_load(own_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : p.epoch;
+    uint32_t epoch = p.epoch;                            // (the device count: wave 4 below)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 16;
     const int n = lane & 15, kg = lane >> 4;
+    // ---- wave 4 fetches the call's count while waves 0-3 multiply.  Agent-scope accesses: the word was written by a
+    // workgroup of the previous launch, possibly on another XCD - a round trip to memory that a GEMM wave would have to sit
+    // out (the compiler waits for an atomic load at once).  The new count goes back at once: nobody else reads it during
+    // this launch, and a store at the end would be the last thing the launch waits for.
+    if (wv == 4 && own_epoch) {
+        const uint32_t e = __hip_atomic_load(own_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (lane == 0) {
+            __hip_atomic_store(own_epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            epoch_s = e;
+        }
+    }
     // ---- GEMM: this wave's share of the K steps
     const int steps = p.K / 32;
-    const int s0 = steps * wv / 4, s1 = steps * (wv + 1) / 4;
+    const int s0 = wv < 4 ? steps * wv / 4 : 0, s1 = wv < 4 ? steps * (wv + 1) / 4 : 0;
     const bool rowok = row0 + n < p.T;
     const uint16_t* xrow = reinterpret_cast<const uint16_t*>(R.x) + (int64_t)(rowok ? row0 + n : 0) * R.x_row_stride + 8 * kg;
     const uint16_t* wrow[4];
@@ -95,15 +105,17 @@ __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams 
         }
     }
     // acc[j][r] = partial out[row0 + n][col0 + 16 j + 4 kg + r]
+    if (wv < 4)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&red[wv][n][16 * j + 4 * kg]) = acc[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&red[wv][n][16 * j + 4 * kg]) = acc[j];
     __syncthreads();
+    if (own_epoch) epoch = epoch_s;
 
     // ---- push: thread (half, idx) holds row idx / 8, columns 8 (idx % 8) .. + 8; the two halves serve alternate peers
     const int half = threadIdx.x >> 7, idx = threadIdx.x & 127;
     const int row = idx >> 3, c8 = (idx & 7) * 8;
     const int parity = epoch & 1u;
-    const bool live = row0 + row < p.T;
+    const bool live = row0 + row < p.T && threadIdx.x < 256;       // (wave 4 has no part in the push and the reduction)
     {
         float v[8];
 #pragma unroll
@@ -146,7 +158,6 @@ __global__ __launch_bounds__(256) void oproj_allreduce_kernel(const OprojParams 
         const u32x4 o = {pack16<F16>(s[0], s[1]), pack16<F16>(s[2], s[3]), pack16<F16>(s[4], s[5]), pack16<F16>(s[6], s[7])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(R.out) + (int64_t)(row0 + row) * R.out_row_stride + col0 + c8) = o;
     }
-    if (own_epoch && threadIdx.x == 0) __hip_atomic_store(own_epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace m355
@@ -159,6 +170,11 @@ extern "C" int m355_comm_alloc(int64_t bytes, void** ptr) {
     if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess || !p) { (void)hipGetLastError(); return M355_ERR_LAUNCH; }
     if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return M355_ERR_LAUNCH; }
     *ptr = p;
+    return M355_OK;
+}
+extern "C" int m355_comm_zero(void* ptr, int64_t bytes) {
+    if (!ptr || bytes <= 0) return M355_ERR_INVALID_ARG;
+    if (hipMemset(ptr, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return M355_ERR_LAUNCH; }
     return M355_OK;
 }
 extern "C" int m355_comm_free(void* ptr) {
@@ -220,7 +236,7 @@ extern "C" int m355_oproj_allreduce(const M355OprojRank* ranks, int32_t n_ranks,
     }
     p.world = world; p.T = T; p.N = N; p.K = K; p.T_cap = T_cap; p.epoch = epoch; p.epoch_state = epoch_state; p.error = error;
     const dim3 grid((unsigned)(N / 64), (unsigned)((T + 15) / 16), (unsigned)n_ranks);
-    if (dtype == M355_DTYPE_F16) hipLaunchKernelGGL((oproj_allreduce_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((oproj_allreduce_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (dtype == M355_DTYPE_F16) hipLaunchKernelGGL((oproj_allreduce_kernel<true>), grid, dim3(320), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((oproj_allreduce_kernel<false>), grid, dim3(320), 0, (hipStream_t)stream, p);
     return check_launch();
 }

@@ -66,6 +66,7 @@ SIGNATURES = {
                                     c_void_p]),
     "m355_comm_alloc": (c_int32, [c_int64, POINTER(c_void_p)]),
     "m355_comm_free": (c_int32, [c_void_p]),
+    "m355_comm_zero": (c_int32, [c_void_p, c_int64]),
     "m355_comm_export": (c_int32, [c_void_p, c_void_p]),
     "m355_comm_open": (c_int32, [c_void_p, POINTER(c_void_p)]),
     "m355_comm_close": (c_int32, [c_void_p]),

@@ -134,10 +134,24 @@ class FusedRowParallel:
                 self.recv[r], self.flags[r] = mine if r == self.rank else (self._open(hr), self._open(hf))
             dist.barrier(group=group)
 
+    # Receive buffers and flag arrays are kept for the life of the process: close() hands them to this pool and the next
+    # instance of the same size takes them back (zeroed).  Freeing them is what went wrong: on this stack a normal allocation
+    # that later lands on the address range of a freed UNCACHED one can be read through stale 4 KiB translations - seen as
+    # whole pages of an input tensor holding old data (tests that created and destroyed an instance per case).
+    _pool: dict = {}
+
     def _alloc(self, nbytes: int) -> int:
+        spare = FusedRowParallel._pool.get((self.device.index, nbytes))
+        if spare:
+            ptr = spare.pop()
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize()
+                self._lib.check(self._L.m355_comm_zero(ptr, nbytes), "m355_comm_zero")
+            self._own.append((ptr, nbytes))
+            return ptr
         p = ctypes.c_void_p()
         self._lib.check(self._L.m355_comm_alloc(nbytes, ctypes.byref(p)), "m355_comm_alloc")
-        self._own.append(p.value)
+        self._own.append((p.value, nbytes))
         return p.value
 
     def _export(self, ptr: int) -> bytes:
@@ -145,17 +159,23 @@ class FusedRowParallel:
         self._lib.check(self._L.m355_comm_export(ptr, buf), "m355_comm_export")
         return buf.raw
 
+    _peer_maps: dict = {}             # (device, handle) -> address: a peer's buffer stays mapped once opened (same reason)
+
     def _open(self, handle: bytes) -> int:
+        key = (self.device.index, bytes(handle))
+        if key in FusedRowParallel._peer_maps:
+            return FusedRowParallel._peer_maps[key]
         p = ctypes.c_void_p()
         self._lib.check(self._L.m355_comm_open(ctypes.create_string_buffer(handle, 64), ctypes.byref(p)), "m355_comm_open")
-        self._opened.append(p.value)
+        FusedRowParallel._peer_maps[key] = p.value
         return p.value
 
     def close(self) -> None:
-        for p in self._opened:
-            self._L.m355_comm_close(p)
-        for p in self._own:
-            self._L.m355_comm_free(p)
+        if self._own:
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize()
+        for p, nbytes in self._own:
+            FusedRowParallel._pool.setdefault((self.device.index, nbytes), []).append(p)
         self._opened, self._own = [], []
 
     def _entries(self, n: int):

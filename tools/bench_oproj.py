@@ -13,7 +13,7 @@ from mi355_attn.tp import FusedRowParallel  # noqa: E402
 dev = "cuda:0"
 Ts = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "16,64,256").split(",")]
 Ks = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "512,2048,4096").split(",")]
-f = FusedRowParallel(4096, t_cap=256, local_world=1, device=dev)
+f = FusedRowParallel(4096, t_cap=256, local_world=1, device=dev, device_epoch=os.environ.get("DEVICE_EPOCH", "1") != "0")
 for T in Ts:
     for K in Ks:
         x = torch.randn((T, K), device=dev, dtype=torch.bfloat16)
