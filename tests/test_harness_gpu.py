@@ -88,9 +88,9 @@ def test_tp2_rehearsal_matches_tp1_first_tokens():
     env = dict(os.environ, M355_BENCH_REHEARSE="1")
     one = subprocess.run([sys.executable, script] + args, capture_output=True, text=True, timeout=60)
     two = _run_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                      "127.0.0.1", "--master-port", "29517", script] + args, env, 90)
+                      "127.0.0.1", "--master-port", "29517", script] + args, env, 60)
     if two is None:
-        pytest.skip("the two-rank gloo run did not finish on this box within 90 s")
+        pytest.skip("the two-rank gloo run did not finish on this box within 60 s")
     assert one.returncode == 0 and "correctness: PASS" in one.stdout, one.stdout[-2000:] + one.stderr[-2000:]
     assert two.returncode == 0 and "correctness: PASS" in two.stdout, two.stdout[-2000:] + two.stderr[-2000:]
     first = lambda out: [int(x) for x in re.findall(r"Prompt \d+ =+ \[(\d+)", out)]
@@ -107,7 +107,7 @@ def test_tp2_graphed_decode_with_the_fused_epilogue():
             "--output-len", "8", "--cut-len", "32"]
     env = dict(os.environ, M355_BENCH_REHEARSE="1")
     two = _run_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                      "127.0.0.1", "--master-port", "29519", script] + args, env, 100)
+                      "127.0.0.1", "--master-port", "29519", script] + args, env, 60)
     if two is None:
         pytest.skip("the two ranks' kernels did not run side by side on this one GPU (every bounded wait ran out)")
     if "fused row-parallel waits gave up: True" in two.stdout:
