@@ -44,8 +44,10 @@ __device__ __forceinline__ u32x4 ld16_sys(const void* p) {
     return v;
 }
 
+// (one workgroup per CU is all a launch has: tell the register allocator, or it packs the loop into 64 registers for an
+// occupancy nobody uses and waits for every load before the next is issued)
 template <bool F16>
-__global__ __launch_bounds__(320) void oproj_allreduce_kernel(const OprojParams p) {
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 4))) void oproj_allreduce_kernel(const OprojParams p) {
     __shared__ __attribute__((aligned(16))) float red[4][16][68];
     __shared__ uint32_t epoch_s;
     const M355OprojRank& R = p.r[blockIdx.z];
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(320) void oproj_allreduce_kernel(const OprojParams 
 #pragma unroll
             for (int j = 0; j < 4; ++j) wa[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[j] + k0));
         }
+        __builtin_amdgcn_sched_barrier(0);                               // every load of the round is out before its first MFMA
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!rowok || s + u >= s1) xb[u] = u32x4{0u, 0u, 0u, 0u};
