@@ -254,7 +254,7 @@ def fused_probe(dev, tp) -> bool:
     env = child_env(23)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused-probe"], env=env, capture_output=True, text=True,
-                           timeout=150)
+                           timeout=120)
         ok = r.returncode == 0 and "FUSED_PROBE_OK" in r.stdout
     except Exception:           # noqa: BLE001  (timeout, spawn failure)
         ok = False
@@ -388,11 +388,12 @@ def one_batch_graph_tp(dev, tp, rank, fused_ok):
     for name, fused, port in (("graph_rccl", False, 29), ("graph_fused_oproj", True, 31)):
         if fused and not fused_ok:
             continue
+        note(rank, f"  {name} (children, at most 170 s)")
         try:
             env = child_env(port)
             env["M355_CHILD_FUSED"] = "1" if fused else "0"
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-batch-graph-child"], env=env,
-                               capture_output=True, text=True, timeout=300)
+                               capture_output=True, text=True, timeout=170)
             lines = [l for l in r.stdout.splitlines() if l.startswith("ONE_BATCH_CHILD ")]
             res = json.loads(lines[-1][len("ONE_BATCH_CHILD "):]) if (r.returncode == 0 and lines) else None
             err = None if r.returncode == 0 else (r.stderr.strip().splitlines() or ["?"])[-1][:300]
@@ -419,7 +420,7 @@ def one_batch_graph_child() -> int:
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo must not go looking up the host name (it may not resolve)
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
     else:
-        dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=300))
+        dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=150))
     import bench_one_batch as ob
     from harness.llama_shell import SHAPES, HarnessRunner
     c = ONE_BATCH_REHEARSAL if rehearse else ONE_BATCH_TP
