@@ -593,12 +593,15 @@ static int prefill_mode() {      // dev build cross-check hook: 1 = row-parallel
 // (splits * T * Hq <= 2^16 rows of D + 4 floats).  The same rule sizes the workspace.  (With 270 blocks - every CU
 // already busy - 4 splits measured no gain: 260 us either way; with 15 blocks 8 splits gave 319 -> 60 us.)
 static int prefill_splits(int64_t T, int32_t Hq, int32_t max_seq_len) {
-    static const int forced = dev_env_int("M355_PREFILL_SPLITS", 0);   // dev build A/B hook: 1 = never
-    if (forced == 1) return 1;
+    static const int forced = dev_env_int("M355_PREFILL_SPLITS", 0);   // dev build A/B hook: 1 = never, n > 1 = n splits
+    if (forced >= 1) return forced > 32 ? 32 : forced;
     const int64_t blocks = (T * Hq + 127) / 128;
     int s = (int)(512 / (blocks > 0 ? blocks : 1));
     if (s > 32) s = 32;
     while (s > 1 && max_seq_len / s < 512) --s;
+    // ... and rather 1 024 while that still leaves 256 workgroups: at 8 pairs per workgroup the ramp and twice the partials
+    // to merge cost more than the second workgroup per CU brings (2 x 32 tokens over 16 384 cached: 58.8 -> 49.8 us)
+    while (s > 1 && max_seq_len / s < 1024 && blocks * (s - 1) >= 256) --s;
     return s < 1 ? 1 : s;
 }
 
