@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define M355_VERSION 212 /* 0.2.12: m355_oproj_allreduce takes an epoch_state; m355_comm_zero */
+#define M355_VERSION 300 /* 0.3.0: m355_decode_plan takes pt_cols; M355_NO_SLOT; M355_PLAN_ERROR_WORD; m355_comm_free pools */
 
 enum {
     M355_OK = 0,
@@ -48,6 +48,12 @@ enum {
  * (every attention entry point and m355_rope_kv_store).  f32 is accepted by m355_kv_store alone. */
 enum { M355_DTYPE_BF16 = 0, M355_DTYPE_F16 = 1, M355_DTYPE_F32 = 2 };
 
+/* out_cache_loc of a token that has no slot (its position lies past the page table's width, see m355_prefill_prepare).
+ * The store kernels wrap negative slots the way torch indexing does (slot + S) and skip whatever is still outside
+ * [0, S): INT64_MIN stays negative after the wrap for every S, so a token marked this way is never written anywhere
+ * (-1 would wrap to the pool's LAST slot). */
+#define M355_NO_SLOT INT64_MIN
+
 int m355_version(void);
 const char *m355_strerror(int code);
 
@@ -56,7 +62,7 @@ const char *m355_strerror(int code);
  * Pools are [S, Hkv, D] contiguous.  k_src / v_src are [T, Hkv*D] with a row stride (they are
  * views of the packed qkv projection, models/llama.py:133-134), inner stride 1, 16-byte aligned
  * rows.  Pure byte copy, bit-exact; negative slots wrap like torch indexing, out-of-range slots
- * are skipped.  dtype selects the element size only (bf16/f16: 2 bytes, f32: 4 bytes). */
+ * (M355_NO_SLOT among them) are skipped.  dtype selects the element size only (bf16/f16: 2 bytes, f32: 4 bytes). */
 int m355_kv_store(void *k_pool, void *v_pool, int64_t pool_row_stride, const void *k_src, const void *v_src,
                   int64_t k_row_stride, int64_t v_row_stride, const int64_t *loc, int32_t T,
                   int32_t Hkv, int32_t D, int64_t S, int32_t dtype, void *stream);
@@ -78,8 +84,8 @@ int m355_out_cache_loc(const int32_t *page_table, int64_t pt_row_stride, const i
  * memory/page_manager.py:45-46); positions[cu_q[r] + j] = prefix_len_r + j;
  * row_of_token[...] = row_r; out_cache_loc[...] as above.  All outputs int64.
  * pt_cols = columns of the table (PageManager.max_page_num, memory/page_manager.py:21; <= pt_row_stride): entries
- * at or past it are not written and the token's out_cache_loc is -1, so a request longer than the table is wide can
- * never spill into the next request's row (the reference raises on the shape mismatch at page_manager.py:46; the
+ * at or past it are not written and the token's out_cache_loc is M355_NO_SLOT (which m355_kv_store and
+ * m355_rope_kv_store skip), so a request longer than the table is wide can never spill into the next request's row (the reference raises on the shape mismatch at page_manager.py:46; the
  * host planner here raises first). */
 int m355_prefill_prepare(int32_t *page_table, int64_t pt_row_stride, int32_t pt_cols, const int32_t *plan,
                          const int32_t *pages, const int32_t *cu_q, int32_t B, int32_t page_size,
@@ -92,7 +98,7 @@ int m355_prefill_prepare(int32_t *page_table, int64_t pt_row_stride, int32_t pt_
  *     out_cache_loc[b] = page_table[rows[b], positions[b] / page_size] * page_size + positions[b] % page_size
  * new_pages[b] is the page the host allocator popped for request b, or -1 when the new token
  * still fits its last page (memory/kvcache.py:49-56).  pt_cols: as m355_prefill_prepare (a position past the table's
- * width writes nothing and gets out_cache_loc -1; the reference raises an index error at page_manager.py:54). */
+ * width writes nothing and gets out_cache_loc M355_NO_SLOT; the reference raises an index error at page_manager.py:54). */
 int m355_decode_prepare(int32_t *page_table, int64_t pt_row_stride, int32_t pt_cols, const int64_t *rows,
                         const int64_t *seq_lens_in, int64_t *seq_lens_out, const int32_t *new_pages,
                         int32_t B, int32_t page_size, int64_t *positions, int64_t *out_cache_loc,
@@ -144,12 +150,23 @@ int m355_decode_attn(const void *q, int64_t q_row_stride, const void *k_pool, co
  *   m355_decode_plan          once per forward, after the page table is final: builds `plan` (device memory of
  *                             m355_decode_plan_bytes bytes, 16-byte aligned) from seq_lens / page_table_ids /
  *                             page_table.  token_capacity must be >= sum(seq_lens) (a smaller value truncates).
+ *                             pt_cols = columns of the table (as m355_prefill_prepare; <= pt_row_stride): a request
+ *                             longer than pt_cols * page_size tokens is attended up to the row's end only - no look-up
+ *                             ever leaves its row - and, like a request the capacity cut, it is left out of the fused
+ *                             KV store (m355_decode_store_attn_planned writes nothing for it).
  *   m355_decode_attn_planned  once per layer, after m355_kv_store; same B, Hq, Hkv, D, token_capacity as the plan.
  *                             workspace: m355_decode_planned_workspace_bytes bytes, fp32 partials. */
 int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity);
 int m355_decode_plan(const int64_t *seq_lens, const int64_t *page_table_ids, const int32_t *page_table,
-                     int64_t pt_row_stride, int32_t B, int32_t page_size, int32_t Hkv, int32_t D, int32_t G,
-                     int64_t token_capacity, void *plan, int64_t plan_bytes, void *stream);
+                     int64_t pt_row_stride, int32_t pt_cols, int32_t B, int32_t page_size, int32_t Hkv, int32_t D,
+                     int32_t G, int64_t token_capacity, void *plan, int64_t plan_bytes, void *stream);
+/* The plan's int32 word M355_PLAN_ERROR_WORD is 0 after m355_decode_plan.  The single-launch decode kernel hands
+ * partial results of requests cut by a workgroup boundary from one workgroup to another; every wait in it is bounded,
+ * and a wait that runs out (never seen on hardware; it would take another tenant holding CUs for seconds) sets this
+ * word to 1 instead of hanging the GPU - the attention output of that launch is then not to be trusted.  Callers that
+ * want to know copy the word back (4 bytes at plan + 4 * M355_PLAN_ERROR_WORD) whenever they next synchronise;
+ * mi355_attn exposes it as DecodePlan.error() / MI355AttnBackend.check(). */
+#define M355_PLAN_ERROR_WORD 6
 int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                             int64_t token_capacity);
 int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                     pc[k * 4 + 2] = hi - lo;
                     pc[k * 4 + 3] = (lo == cs && hi == ce) ? -1 : pbase[bb] + (r - cs / Rt);
                 }
-                const unsigned long long ends = __ballot(have && hi == ce);
+                const unsigned long long ends = __ballot(have && hi == ce && plan[p.off_full + bb] != 0);
                 endmask = 0;
                 for (int j = 0, k = 0; j < kMaxPieces; ++j)
                     if ((mask >> j) & 1ull) { endmask |= (uint32_t)((ends >> j) & 1ull) << k; ++k; }

@@ -41,6 +41,12 @@ __device__ __forceinline__ int ub_minus1(const int32_t* cum, int n, int32_t x) {
     return lo;
 }
 __device__ __forceinline__ int32_t stages_of(int32_t tokens) { return (tokens + kStageTok - 1) / kStageTok; }
+// shares 0 .. rem-1 hold Q + 1 stages of the stream, the others Q
+__device__ __forceinline__ int32_t share_start(int32_t i, int32_t Q, int32_t rem) { return i * Q + (i < rem ? i : rem); }
+__device__ __forceinline__ int32_t share_of(int32_t v, int32_t Q, int32_t rem) {
+    const int32_t big = rem * (Q + 1);
+    return v < big ? v / (Q + 1) : rem + (v - big) / Q;
+}
 
 // ------------------------------------------------------------------------------------------------
 // plan
@@ -51,7 +57,7 @@ __device__ __forceinline__ int32_t stages_of(int32_t tokens) { return (tokens + 
 // only ever cut at a multiple of 32 of its own tokens (no cut adds a partial stage).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nb,
-                                                          int32_t Hkv, int32_t W, int64_t cap, int32_t* __restrict__ plan,
+                                                          int32_t Hkv, int32_t W, int64_t cap, int64_t wmax, int32_t* __restrict__ plan,
                                                           ShareLayout L) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t cum_s[kShareCumLds + 1];
@@ -78,16 +84,18 @@ __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restr
     int32_t* nz = plan + L.nz;
     const int per = (B + 1023) / 1024;
     const int lo = tid * per, hi = min(B, lo + per);
-    // ---- cum: exclusive prefix sums of the lengths, clamped so the stream never exceeds the capacity
+    // ---- cum: exclusive prefix sums of the lengths, clamped so the stream never exceeds the capacity; a request longer
+    // than its page-table row is wide (wmax tokens) is cut at the row's end: nothing past the row is ever looked up
+    auto len_of = [&](int b) -> int32_t { const int64_t l = seq_lens[b]; return (int32_t)(l < wmax ? (l > 0 ? l : 0) : wmax); };
     int32_t s = 0;
-    for (int b = lo; b < hi; ++b) s += (int32_t)seq_lens[b];
+    for (int b = lo; b < hi; ++b) s += len_of(b);
     int32_t run = block_scan(s);
     const int32_t icap = (int32_t)cap;
     for (int b = lo; b < hi; ++b) {
         const int32_t c = run < icap ? run : icap;
         cum[b] = c;
         if (staged) cum_s[b] = c;
-        run += (int32_t)seq_lens[b];
+        run += len_of(b);
     }
     if (tid == 1023) { const int32_t c = run < icap ? run : icap; cum[B] = c; if (staged) cum_s[B] = c; }
     __syncthreads();
@@ -108,15 +116,17 @@ __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restr
     __syncthreads();
     const int32_t* sg = staged ? stg_s : stg;
     const int32_t TS = sg[B];
-    int32_t Q = (TS + nb - 1) / nb;
-    Q = Q < kShareMinStages ? kShareMinStages : Q;
+    // shares of Q or Q + 1 stages (the first `rem` get the extra one): every workgroup streams within one stage of the
+    // same amount.  A stream too short for that is dealt in shares of kShareMinStages, the last workgroups idle.
+    int32_t Q = TS / nb, rem = TS - Q * nb;
+    if (Q < kShareMinStages) { Q = kShareMinStages; rem = 0; }
     // ---- shares (nb <= 1024: one per thread): the first and the last request that have stages in it
     if (tid < nb) {
         int32_t* e = plan + L.share + (int64_t)tid * kShareW;
-        const int64_t s0 = (int64_t)tid * Q;
+        const int64_t s0 = share_start(tid, Q, rem);
         int32_t bf = 0, bl = -1;
         if (s0 < TS) {
-            const int32_t s1 = (int32_t)min((int64_t)TS, s0 + Q);
+            const int32_t s1 = (int32_t)min((int64_t)TS, s0 + Q + (tid < rem));
             bf = ub_minus1(sg, B, (int32_t)s0);
             bl = ub_minus1(sg, B, s1 - 1);
         }
@@ -125,16 +135,16 @@ __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restr
     }
     if (tid == 0) {
         plan[kHTotal] = cu[B]; plan[kHShareStages] = Q; plan[kHB] = B; plan[kHShares] = nb; plan[kHWaves] = W;
-        plan[kHStages] = TS; plan[kHError] = 0;
-        for (int k = kHError + 1; k < kShareHdr; ++k) plan[k] = 0;
+        plan[kHStages] = TS; plan[kHError] = 0; plan[kHShareRem] = rem;
+        for (int k = kHShareRem + 1; k < kShareHdr; ++k) plan[k] = 0;
     }
 }
 
 __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restrict__ page_table, int64_t pt_stride,
-                                                         const int64_t* __restrict__ rows, int32_t B, int32_t ps, int32_t W,
-                                                         int32_t* __restrict__ plan, ShareLayout L) {
+                                                         const int64_t* __restrict__ rows, const int64_t* __restrict__ seq_lens,
+                                                         int32_t B, int32_t ps, int32_t W, int32_t* __restrict__ plan, ShareLayout L) {
     __shared__ int32_t cum_s[kShareCumLds + 1];
-    const int32_t T = plan[kHTotal], Q = plan[kHShareStages], TS = plan[kHStages];
+    const int32_t T = plan[kHTotal], Q = plan[kHShareStages], TS = plan[kHStages], rem = plan[kHShareRem];
     const int32_t* cum = plan + L.cum;
     const int32_t* stg = plan + L.stg;
     const int32_t* nz = plan + L.nz;
@@ -150,8 +160,8 @@ __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restri
         const int32_t tok = g - cum[b], len = cum[b + 1] - cum[b];
         const int32_t sb0 = stg[b], sb1 = stg[b + 1];
         const int32_t v = sb0 + tok / kStageTok, idx = tok % kStageTok;      // stage of the stream, place inside it
-        const int32_t i = v / Q;
-        const int32_t s0 = i * Q, s1 = min(TS, s0 + Q);
+        const int32_t i = share_of(v, Q, rem);
+        const int32_t s0 = share_start(i, Q, rem), s1 = min(TS, s0 + Q + (i < rem));
         const int32_t a = max(sb0, s0), e = min(sb1, s1);                     // the segment = this request's stages in the share
         const int32_t st = v - a, seg_n = e - a;
         const int32_t sl = (s1 - e) + st;                                     // the share's segments are walked last to first
@@ -164,7 +174,9 @@ __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restri
             int32_t meta = min(kStageTok, len - (tok / kStageTok) * kStageTok);
             if (st < W) meta |= kRecFirst;                              // the owning wave's previous stage lies before the segment
             if (st + W >= seg_n) meta |= kRecLast;                      // ... its next one behind it
-            if (v == sb1 - 1) meta |= kRecNewest;                       // the request's last stage holds its newest token
+            // the request's last stage holds its newest token - unless the request was cut (capacity, table width): then the
+            // fused store has no slot to write and leaves the pools alone
+            if (v == sb1 - 1 && (int64_t)len == seq_lens[b]) meta |= kRecNewest;
             rec[kRecB] = b;
             rec[kRecMeta] = meta;
             rec[kRecOrd] = nz[bl] - nz[b];
@@ -246,8 +258,9 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
     }
     const int Q = __builtin_amdgcn_readfirstlane(p.plan[kHShareStages]);
     const int TS = __builtin_amdgcn_readfirstlane(p.plan[kHStages]);
-    const int SO = share * Q;                                        // the share = stages [SO, SO + NS) of the stream
-    const int NS = TS - SO < Q ? TS - SO : Q;
+    const int rem = __builtin_amdgcn_readfirstlane(p.plan[kHShareRem]);
+    const int SO = share_start(share, Q, rem);                       // the share = stages [SO, SO + NS) of the stream
+    const int NS = TS - SO < Q + (share < rem) ? TS - SO : Q + (share < rem);
     if (NS <= 0) { wait_vmcnt<0>(); return; }                        // (no LDS-DMA may outlive its wave)
     shstamp<STAMP>(p, wave, 1);
 
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
         int cross_left = 0, cross_next = share - 1;
         {
             const int f0 = __builtin_amdgcn_readfirstlane(stg[bf]);
-            if (f0 < SO && __builtin_amdgcn_readfirstlane(stg[bf + 1]) <= S1) cross_left = share - f0 / Q;   // shares f0/Q .. share-1 publish
+            if (f0 < SO && __builtin_amdgcn_readfirstlane(stg[bf + 1]) <= S1) cross_left = share - share_of(f0, Q, rem);   // the shares from f0's up to share-1 publish
         }
         float cm = kNegBig, cl = 0.f, cacc[VEC];
 #pragma unroll
@@ -283,12 +296,15 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
         // launch.  Measured on configs[1] (one box, stamps): with a lag of 20 polls a load -> look cycle takes ~2.5 us
         // and 112 of 248 merging workgroups finished their hand-off AFTER their last stage (+1.4 us); lag 6: 21, lag 2:
         // 10, tail p95 2.4 -> 1.5 us - and the same launch time, which the slowest streaming waves set.
-        constexpr int kCrossLag = 4;
+#ifndef M355_CROSS_LAG
+#define M355_CROSS_LAG 4
+#endif
+        constexpr int kCrossLag = M355_CROSS_LAG;
         int cstate = 0, cage = 0;
         unsigned long long cg[NG];
 #pragma unroll
         for (int x = 0; x < NG; ++x) cg[x] = 0ull;
-        auto cross_step = [&](const bool hurry) {
+        auto cross_step = [&](const bool hurry, const bool look = true) {
             unsigned long long* src = gran + (int64_t)cross_next * (NG * 64) + lane;
             if (cstate == 0) {
 #pragma unroll
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                 cstate = 1; cage = 0;
                 return;
             }
-            if (!hurry && ++cage < kCrossLag) return;
+            if (!hurry && (++cage < kCrossLag || !look)) return;
             bool mine = true;
 #pragma unroll
             for (int x = 0; x < NG; ++x) mine = mine && (uint32_t)(cg[x] >> 32) == 1u;
@@ -336,30 +352,36 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             base += nst;
             int32_t* const arrived = ctl + 2 + ord % p.nslot;
             int spins = 0;
-            while (lds_peek(arrived) < e) {                          // the segment's waves; meanwhile, the hand-off
-                if (cross_left > 0) cross_step(false);
+            int seen;
+            while ((seen = lds_peek(arrived)) < e) {                 // the segment's waves; meanwhile, the hand-off - but only
+                // while none of them has arrived: looking at granules means waiting for their loads (microseconds on a
+                // streaming CU), and the first arrival says the others are about to follow
+                if (cross_left > 0) cross_step(false, seen == 0);     // (asking for granules never waits; looking at them does)
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > kPollLimit) { failed = true; break; }
             }
             asm volatile("" ::: "memory");
             if (ord == 0) shstamp<STAMP>(p, wave, 2);
             if (b == bf) shstamp<STAMP>(p, wave, 4);
-            // all partials of the segment are requested at once (one LDS latency, not one per wave: a share of many short
-            // requests merges a segment every few hundred cycles, and its streaming waves wait for their partial slots)
+            // All partials of the segment are requested at once, as whole vectors and from addresses that hold a partial for
+            // EVERY w (a wave that took no part stands in wave `first`'s and gets weight 0): no branches, ONE LDS latency.
+            // (Selecting the loaded values instead made hipcc branch around each load and wait for each wave's reads in
+            // turn: 0.8 us per segment, and on the last segment of the last workgroup that is the launch's tail.)
             const float* slot = parts + (ord % p.nslot) * W * S::PW;
             constexpr int WMAX = share_max_waves(D);
-            float pm[WMAX], pl[WMAX], pa[WMAX][VEC];
+            typedef float fvec __attribute__((ext_vector_type(VEC)));
+            float pm[WMAX], pl[WMAX];
+            fvec pa[WMAX];
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) {
                 int rel = w - first;
                 rel += rel < 0 ? W : 0;
                 const bool part = w < W && rel < e;                  // wave w streamed a piece of this segment
                 const float* pw = slot + (part ? w : first) * S::PW;
-                const float m_ = pw[G * D + g], l_ = pw[G * D + G + g];
-#pragma unroll
-                for (int x = 0; x < VEC; ++x) pa[w][x] = part ? pw[e0 + x] : 0.f;
+                pa[w] = *reinterpret_cast<const fvec*>(pw + e0);
+                const float m_ = pw[G * D + g];
+                pl[w] = pw[G * D + G + g];
                 pm[w] = part ? m_ : kNegBig;
-                pl[w] = part ? l_ : 0.f;
             }
             float gm = pm[0];
 #pragma unroll
@@ -369,12 +391,14 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             for (int x = 0; x < VEC; ++x) acc[x] = 0.f;
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) {
-                const float wgt = exp2_fast(pm[w] - gm);             // (absent waves: 2^(-1e30 - gm) = 0 on zeros)
+                const float wgt = exp2_fast(pm[w] - gm);             // (absent waves: 2^(-1e30 - gm) = 0, times a finite stand-in)
                 den = fmaf(wgt, pl[w], den);
 #pragma unroll
                 for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, pa[w][x], acc[x]);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef M355_TAIL_STAMPS
+            if (b == bf) shstamp<STAMP>(p, wave, 6);
+#endif
             if (lane == 0) {                                         // slot free: count back to zero first, then release
                 __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -406,7 +430,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                 for (int x = 0; x < VEC; ++x) acc[x] = cacc[x] * wa + acc[x] * wb;
             }
             {
-                const float inv = 1.f / den;
+                const float inv = __builtin_amdgcn_rcpf(den);        // (one instruction, 1 ulp; the division is a dozen)
                 uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)(h * G + g) * D + d0;
                 if constexpr (VEC == 1) {
                     *op = (uint16_t)(pack16<F16>(acc[0] * inv, 0.f) & 0xffffu);
@@ -423,6 +447,9 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                     }
                 }
             }
+#ifdef M355_TAIL_STAMPS
+            if (b == bf) shstamp<STAMP>(p, wave, 7);
+#endif
             ++ord;
         }
         if (failed && lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(p.plan) + kHError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -596,6 +623,8 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             const int ord = __builtin_amdgcn_readfirstlane(rc[kRecOrd]);
             int spins = 0;
             while (lds_peek(ctl + 1) < ord - p.nslot + 1 && ++spins < kPollLimit) __builtin_amdgcn_s_sleep(1);   // slot still being merged
+            if (spins >= kPollLimit && lane == 0)               // gave up: the slot is overwritten while it is merged - say so
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(p.plan) + kHError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float* dst = parts + ((ord % p.nslot) * W + j) * S::PW;
             if (n < G) {
 #pragma unroll
@@ -616,10 +645,13 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
     // One stage per wave in flight (eight per CU): measured as fast as two, with half the spread between the waves of
     // a workgroup, and every wait is a plain vmcnt(0).  The ring has two slots so that stage s+1 can be asked for as
     // soon as stage s has landed, before it is consumed.
-    __syncthreads();                                     // ctl is zero for everyone (nothing reads it before a first flush)
     wait_vmcnt<0>();
     shstamp<STAMP>(p, wave, 2);
+    if constexpr (STAMP)                                 // (timing build: which XCD this workgroup runs on, slot 6 of its streaming waves)
+        if (p.stamps && lane == 0)
+            p.stamps[((size_t)blockIdx.x * (kShareMaxWaves + 1) + wave) * 8 + 6] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
     issue(0);
+    __syncthreads();                                     // ctl is zero for everyone (nothing reads it before a first flush)
     for (int s = 0; s < Nw; ++s) {
         wait_vmcnt<0>();
         if (s == 0) shstamp<STAMP>(p, wave, 3);
@@ -658,15 +690,15 @@ ShareShape share_shape(int Hkv, int D, int G) {
     return r;
 }
 
-int launch_share_plan(const int64_t* seq_lens, const int64_t* rows, const int32_t* page_table, int64_t pt_stride, int32_t B,
-                      int32_t ps, int32_t Hkv, int32_t D, int32_t G, int64_t cap, int32_t* plan, hipStream_t st) {
+int launch_share_plan(const int64_t* seq_lens, const int64_t* rows, const int32_t* page_table, int64_t pt_stride, int32_t pt_cols,
+                      int32_t B, int32_t ps, int32_t Hkv, int32_t D, int32_t G, int64_t cap, int32_t* plan, hipStream_t st) {
     const ShareShape sh = share_shape(Hkv, D, G);
     if (!sh.ok) return M355_ERR_UNSUPPORTED;
     const ShareLayout L = share_layout(B, sh.nb, Hkv, cap, D, G);
-    hipLaunchKernelGGL(share_plan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, sh.nb, Hkv, sh.W, cap, plan, L);
+    hipLaunchKernelGGL(share_plan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, sh.nb, Hkv, sh.W, cap, (int64_t)pt_cols * ps, plan, L);
     int64_t blocks = (cap + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(share_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, page_table, pt_stride, rows, B, ps, sh.W, plan, L);
+    hipLaunchKernelGGL(share_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, page_table, pt_stride, rows, seq_lens, B, ps, sh.W, plan, L);
     return check_launch();
 }
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ int32_t pieces_of(int32_t a, int32_t e, int32_t R) { 
 constexpr int kCumLds = 4096;                       // requests whose cumulative lengths the plan kernels stage in LDS
 
 __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nwh,
-                                                         int32_t r_min, int64_t cap, int32_t* __restrict__ plan,
+                                                         int32_t r_min, int64_t cap, int64_t wmax, int32_t* __restrict__ plan,
                                                          PlanLayout L) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t cum_s[kCumLds + 1];                // cum of the first kCumLds requests: the record loop's binary
@@ -83,8 +83,10 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
         return base + incl - mine;
     };
     const bool staged = B <= kCumLds;
+    // a request longer than its page-table row is wide (wmax tokens) is cut at the row's end: nothing past the row is looked up
+    auto len_of = [&](int b) -> int32_t { const int64_t l = seq_lens[b]; return (int32_t)(l < wmax ? (l > 0 ? l : 0) : wmax); };
     int32_t s = 0;
-    for (int b = lo; b < hi; ++b) s += (int32_t)seq_lens[b];
+    for (int b = lo; b < hi; ++b) s += len_of(b);
     int32_t run = block_scan(s);
     // lengths are clamped so the stream never exceeds the slot slabs (a too-small capacity truncates, never overruns)
     const int32_t icap = (int32_t)cap;
@@ -92,12 +94,15 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
         const int32_t c = run < icap ? run : icap;
         cum[b] = c;
         if (staged) cum_s[b] = c;
-        run += (int32_t)seq_lens[b];
+        run += len_of(b);
     }
     if (tid == 1023) { const int32_t c = run < icap ? run : icap; cum[B] = c; if (staged) cum_s[B] = c; }   // the grand total
     __syncthreads();
     const int32_t* cu = staged ? cum_s : cum;
     const int32_t total = cu[B];
+    int32_t* full = plan + L.full;
+    for (int b = lo; b < hi; ++b) full[b] = (int64_t)(cu[b + 1] - cu[b]) == seq_lens[b];
+    if (tid == 1023) full[B] = 0;
     // one range per resident wave; when that would exceed kRMax tokens, k equal ranges per wave (k rounds of the
     // grid-stride loop) rather than kRMax-token ranges whose count is no multiple of the wave count
     const int32_t per_wave = (total + nwh - 1) / nwh;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
             rec[4 + np * 4 + 1] = lo2 - g0;
             rec[4 + np * 4 + 2] = hi2 - lo2;
             rec[4 + np * 4 + 3] = (lo2 == cs && hi2 == ce) ? -1 : pb[b] + (r - cs / R);
-            if (hi2 == ce) endmask |= 1 << np;
+            if (hi2 == ce && (int64_t)(ce - cs) == seq_lens[b]) endmask |= 1 << np;   // (a cut request has no newest slot)
             ++np;
         }
         rec[1] = np;
@@ -595,17 +600,18 @@ extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int
 }
 
 extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_table_ids, const int32_t* page_table,
-                                int64_t pt_row_stride, int32_t B, int32_t page_size, int32_t Hkv, int32_t D, int32_t G,
+                                int64_t pt_row_stride, int32_t pt_cols, int32_t B, int32_t page_size, int32_t Hkv, int32_t D, int32_t G,
                                 int64_t token_capacity, void* plan, int64_t plan_bytes, void* stream) {
     if (B == 0) return M355_OK;
-    if (!seq_lens || !page_table_ids || !page_table || !plan || B < 0 || page_size <= 0 || Hkv <= 0 || token_capacity <= 0)
+    if (!seq_lens || !page_table_ids || !page_table || !plan || B < 0 || page_size <= 0 || Hkv <= 0 || token_capacity <= 0 ||
+        pt_row_stride <= 0 || pt_cols <= 0 || pt_cols > pt_row_stride)
         return M355_ERR_INVALID_ARG;
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
     if (token_capacity > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
     if (share_mode(B, Hkv, D, G, token_capacity)) {
         const ShareLayout SL = share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G);
         if (plan_bytes < SL.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
-        return launch_share_plan(seq_lens, page_table_ids, page_table, pt_row_stride, B, page_size, Hkv, D, G, token_capacity,
+        return launch_share_plan(seq_lens, page_table_ids, page_table, pt_row_stride, pt_cols, B, page_size, Hkv, D, G, token_capacity,
                                  (int32_t*)plan, (hipStream_t)stream);
     }
     const int nwh = stream_nwh(Hkv, D, G, token_capacity);
@@ -613,7 +619,7 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
     if (plan_bytes < L.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, nwh, stream_rmin(D, G), token_capacity,
-                       (int32_t*)plan, L);
+                       (int64_t)pt_cols * page_size, (int32_t*)plan, L);
     int64_t blocks = (token_capacity + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(plan_slots_kernel, dim3((unsigned)blocks), dim3(256), 0, st, page_table, pt_row_stride,
@@ -703,7 +709,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     p.k_new = (const uint16_t*)k_new; p.v_new = (const uint16_t*)v_new; p.kn_stride = k_row_stride; p.vn_stride = v_row_stride;
     p.ws_o = (float*)workspace; p.ws_ml = p.ws_o + n_partials * Hq * D;
     p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = pool_row_stride;
-    p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_rec = L.rec; p.off_slots = L.slots;
+    p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_full = L.full; p.off_rec = L.rec; p.off_slots = L.slots;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.nwh = nwh; p.max_ranges = L.max_ranges; p.scale_log2 = scale * kLog2e;
     p.stamps = M355_STREAM_STAMPS;
     { static const int rot = dev_env_int("M355_STREAM_ROT", 1);    // (dev build, 0: no head rotation, for A/B)
@@ -810,7 +816,10 @@ extern "C" int m355_decode_attn(const void* q, int64_t q_row_stride, const void*
     const int64_t pb = up256(m355_decode_plan_bytes(B, Hkv, D, G, cap));
     const int64_t wb = up256(m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap));
     if (!workspace || workspace_bytes < pb + wb || ((uintptr_t)workspace & 255)) return M355_ERR_WORKSPACE;
-    const int rc = m355_decode_plan(seq_lens, page_table_ids, page_table, pt_row_stride, B, page_size, Hkv, D, G, cap, workspace, pb, stream);
+    // (this form is not told the table's width: its row stride bounds the look-ups, so they never leave the request's row)
+    if (pt_row_stride <= 0 || pt_row_stride > 0x7fffffffLL) return M355_ERR_INVALID_ARG;
+    const int rc = m355_decode_plan(seq_lens, page_table_ids, page_table, pt_row_stride, (int32_t)pt_row_stride, B, page_size, Hkv, D, G, cap,
+                                    workspace, pb, stream);
     if (rc != M355_OK) return rc;
     return m355_decode_attn_planned(q, q_row_stride, k_pool, v_pool, pool_row_stride, workspace, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     cap, (char*)workspace + pb, wb, dtype, stream);

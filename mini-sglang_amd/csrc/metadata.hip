@@ -27,7 +27,8 @@ __device__ __forceinline__ int find_req_by(const int32_t* key, int stride, int B
 }
 
 // A request longer than the table is wide (pt_cols columns) never writes past its row: the out-of-range entries are
-// dropped and its out_cache_loc is -1 (m355_kv_store skips it).  The host planner refuses such a batch first
+// dropped and its out_cache_loc is M355_NO_SLOT (INT64_MIN: still negative after the store kernels' torch-style wrap of
+// negative slots, so m355_kv_store and m355_rope_kv_store skip it; -1 would wrap to the pool's last slot).  The host planner refuses such a batch first
 // (mi355_attn/batch.py; the reference fails on the shape mismatch at memory/page_manager.py:46).
 __global__ __launch_bounds__(256) void prefill_prepare_kernel(int32_t* __restrict__ page_table, int64_t pt_stride, int32_t pt_cols,
                                                               const int32_t* __restrict__ plan,
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void prefill_prepare_kernel(int32_t* __restric
             const int64_t vpn = pos / ps;
             positions[t] = pos;
             row_of_token[t] = row;
-            out_cache_loc[t] = vpn < pt_cols ? (int64_t)pages[plan[r * 4 + 3] + vpn] * ps + (pos - vpn * ps) : (int64_t)-1;
+            out_cache_loc[t] = vpn < pt_cols ? (int64_t)pages[plan[r * 4 + 3] + vpn] * ps + (pos - vpn * ps) : (int64_t)M355_NO_SLOT;
         }
     }
 }
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void decode_prepare_kernel(int32_t* __restrict
     const int64_t vpn = pos / ps;
     seq_lens_out[b] = L;
     positions[b] = pos;
-    if (vpn >= pt_cols) { out_cache_loc[b] = -1; return; }     // past the table's width: nothing written (see above)
+    if (vpn >= pt_cols) { out_cache_loc[b] = M355_NO_SLOT; return; }     // past the table's width: nothing written (see above)
     int32_t* entry = page_table + rows[b] * pt_stride + vpn;
     int32_t page = new_pages[b];
     if (page >= 0) *entry = page;                         // batch.py:331-337
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(1024) void decode_prepare_ring_kernel(int32_t* __re
                 else page = *entry;
                 out_cache_loc[b] = (int64_t)page * ps + (pos - vpn * ps);
             } else {
-                out_cache_loc[b] = -1;                    // past the table's width (the page is still taken: FIFO order holds)
+                out_cache_loc[b] = M355_NO_SLOT;          // past the table's width (the page is still taken: FIFO order holds)
             }
         }
         taken += total;

@@ -21,7 +21,7 @@ constexpr int kShareMaxWaves = 8;               // streaming waves per workgroup
 constexpr int kShareCumLds = 4096;              // requests whose prefix sums the plan kernels stage in LDS
 
 // header words
-constexpr int kHTotal = 0, kHShareStages = 1, kHB = 2, kHShares = 3, kHWaves = 4, kHStages = 5, kHError = 6;
+constexpr int kHTotal = 0, kHShareStages = 1, kHB = 2, kHShares = 3, kHWaves = 4, kHStages = 5, kHError = M355_PLAN_ERROR_WORD, kHShareRem = 7;
 
 // hand-off granules per (kv head, share): one fp32 partial O[G][D] + m, l per lane, 8 bytes {value, tag} each
 __host__ __device__ inline int64_t share_gran_words(int D, int G) { return (int64_t)((G * D / 64 > 0 ? G * D / 64 : 1) + 2) * 64 * 2; }
@@ -73,8 +73,8 @@ struct ShareParams {
     unsigned long long* stamps;   // dev-only timing probe (tools/stamp_share.py), 8 slots per wave; else nullptr
 };
 
-int launch_share_plan(const int64_t* seq_lens, const int64_t* rows, const int32_t* page_table, int64_t pt_stride, int32_t B,
-                      int32_t ps, int32_t Hkv, int32_t D, int32_t G, int64_t cap, int32_t* plan, hipStream_t st);
+int launch_share_plan(const int64_t* seq_lens, const int64_t* rows, const int32_t* page_table, int64_t pt_stride, int32_t pt_cols,
+                      int32_t B, int32_t ps, int32_t Hkv, int32_t D, int32_t G, int64_t cap, int32_t* plan, hipStream_t st);
 int launch_share_attn(ShareParams& p, int D, int G, bool f16, hipStream_t st, bool stamp = false);
 
 }  // namespace m355

@@ -31,9 +31,11 @@ struct MG {
     __host__ __device__ static constexpr int sV(int row) { return ((row / SPAN) % (C / 2)) * 2; }
 };
 
-// plan buffer (int32 words): hdr[8] | cum[B+1] | pbase[B+1] | rec[max_ranges][kRec] | slots[max_ranges][kRMax]
+// plan buffer (int32 words): hdr[8] | cum[B+1] | pbase[B+1] | full[B+1] | rec[max_ranges][kRec] | slots[max_ranges][kRMax]
+// full[b] = 1 when the whole of request b is in the stream (0: cut by the capacity or by the page table's width - its
+// newest token then has no slot the fused store could write).  hdr[M355_PLAN_ERROR_WORD] stays 0: this form never waits.
 struct PlanLayout {
-    int64_t cum, pbase, rec, slots, ints;
+    int64_t cum, pbase, full, rec, slots, ints;
     int32_t max_ranges;
 };
 __host__ __device__ inline PlanLayout plan_layout(int32_t B, int32_t nwh, int64_t cap) {
@@ -41,7 +43,8 @@ __host__ __device__ inline PlanLayout plan_layout(int32_t B, int32_t nwh, int64_
     L.max_ranges = (int32_t)(nwh + cap / kRMax + 2);
     L.cum = kHdrInts;
     L.pbase = L.cum + (B + 1);
-    L.rec = (L.pbase + (B + 1) + 3) & ~(int64_t)3;
+    L.full = L.pbase + (B + 1);
+    L.rec = (L.full + (B + 1) + 3) & ~(int64_t)3;
     L.slots = L.rec + (int64_t)L.max_ranges * kRec;
     L.ints = L.slots + (int64_t)L.max_ranges * kRMax;
     return L;
@@ -59,7 +62,7 @@ struct StreamParams {
     float* ws_o;    // [n_partials, Hq, D]
     float* ws_ml;   // [n_partials, Hq, 2]
     int64_t q_stride, o_stride, row_elems;
-    int64_t off_cum, off_pbase, off_rec, off_slots;
+    int64_t off_cum, off_pbase, off_full, off_rec, off_slots;
     int32_t B, Hq, Hkv, nwh, max_ranges;
     int32_t rot;                  // kv head of workgroup (w, j) = (j + w / rot) % Hkv; 0 = no rotation
     float scale_log2;

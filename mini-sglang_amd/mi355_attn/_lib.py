@@ -17,6 +17,9 @@ LIB_PATH = {"": _DEFAULT, "dev": DEV_LIB_PATH}.get(os.environ.get("M355_LIB_PATH
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
+NO_SLOT = -(1 << 63)                 # M355_NO_SLOT (include/mi355attn.h): out_cache_loc of a token without a slot
+PLAN_ERROR_WORD = 6                  # M355_PLAN_ERROR_WORD
+
 MAX_RANKS = 8                        # M355_MAX_RANKS (include/mi355tp.h)
 
 
@@ -47,7 +50,7 @@ SIGNATURES = {
                                    c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
                                    c_void_p, c_int64, c_int32, c_void_p]),
     "m355_decode_plan_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
-    "m355_decode_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
+    "m355_decode_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int64, c_void_p, c_int64, c_void_p]),
     "m355_decode_planned_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
     "m355_decode_attn_planned": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,

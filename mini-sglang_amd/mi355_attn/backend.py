@@ -111,6 +111,15 @@ class MI355AttnBackend:
         self.forward_metadata = ForwardMetadata(decode=False, max_seq_len=max(lens),
                                                 max_extend_len=max(s - p for s, p in zip(lens, pre)), cu_q=cu_q)
 
+    def check(self) -> None:
+        """Raise if a launch over the current decode plan gave up a bounded cross-workgroup wait (the plan's
+        M355_PLAN_ERROR_WORD; include/mi355attn.h) - its attention output is then wrong.  One 4-byte read-back, i.e. a
+        device sync: call it where the engine synchronises anyway (after sampling, scheduler.py:416 `.tolist()`)."""
+        md = self.forward_metadata
+        if md is not None and md.plan is not None and md.plan.error():
+            raise ops._lib.MI355AttnError("MI355AttnBackend: a decode launch gave up waiting for another workgroup's partial "
+                                          "result (plan error word set): the outputs of this forward are invalid")
+
     # ---- per layer ------------------------------------------------------------------------------
     def forward(self, q, k, v, layer, batch):
         if batch.mode.is_decode():

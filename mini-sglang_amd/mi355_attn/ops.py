@@ -215,6 +215,12 @@ class DecodePlan:
     def __init__(self, buf, B, Hkv, D, G, capacity):
         self.buf, self.B, self.Hkv, self.D, self.G, self.capacity = buf, B, Hkv, D, G, capacity
 
+    def error(self) -> int:
+        """The plan's give-up word (M355_PLAN_ERROR_WORD): non-zero when a bounded cross-workgroup wait of the single-launch
+        decode kernel ran out in some launch over this plan - that launch's output is not to be trusted.  Reads device
+        memory: a sync, so call it where one is paid anyway (tests, the end of a forward, MI355AttnBackend.check())."""
+        return int(self.buf[4 * _lib.PLAN_ERROR_WORD: 4 * _lib.PLAN_ERROR_WORD + 4].view(torch.int32).item())
+
 
 def decode_plan(page_table: torch.Tensor, page_table_ids: torch.Tensor, seq_lens: torch.Tensor, page_size: int,
                 num_heads: int, num_kv_heads: int, head_dim: int, token_capacity: int,
@@ -230,7 +236,7 @@ def decode_plan(page_table: torch.Tensor, page_table_ids: torch.Tensor, seq_lens
     if buf is None or buf.numel() * buf.element_size() < need:
         buf = torch.empty(need, dtype=torch.uint8, device=seq_lens.device)
     check(lib.m355_decode_plan(seq_lens.data_ptr(), page_table_ids.data_ptr(), page_table.data_ptr(),
-                               page_table.stride(0), B, page_size, num_kv_heads, head_dim, G, token_capacity,
+                               page_table.stride(0), page_table.shape[1], B, page_size, num_kv_heads, head_dim, G, token_capacity,
                                buf.data_ptr(), buf.numel() * buf.element_size(), current_stream()), "m355_decode_plan")
     return DecodePlan(buf, B, num_kv_heads, head_dim, G, token_capacity)
 

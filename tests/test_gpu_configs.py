@@ -1,7 +1,8 @@
 """GPU parity at BASELINE.json's own workloads and through the objects the reference hands a backend.
 
   cfg1  Llama-3.2-1B shape, page_size 1, batch 1, 128-token prompt + 16 decode steps (also the golden flow ps1_1b)
-  cfg5  Llama-3-70B / TP8 per-rank shape (8, 1, 128), every request 32 768 tokens, B in {1, 8}
+  cfg3  Llama-3-8B shape, 4 groups x 4 requests over a shared 1024-token cached prefix, at full size, then 4 decode steps
+  cfg5  Llama-3-70B / TP8 per-rank shape (8, 1, 128), every request 32 768 tokens, B in {1, 8, 32}
   the reference's own Batch / KVCache shapes (no host mirrors, separate pool tensors per layer)
   PagedRadixCache -> prefix_ppns -> shared physical pages -> HIP prefill
   the device page ring at a batch larger than one round of its kernel
@@ -181,6 +182,90 @@ def test_cfg5_70b_tp8_32k_decode(B):
     o2 = ops.decode_attn_planned(dq, dkp, dvp, plan, Hq)
     torch.cuda.synchronize()
     np.testing.assert_allclose(o2.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    assert plan.error() == 0
+
+
+def test_cfg5_70b_tp8_32k_decode_B32_share_kernel():
+    """configs[4] per rank at B = 32: the size bench.py quotes for cfg5 (1 M cached tokens, 512 MiB of K/V per layer).  The
+    library serves it with the single-launch SHARE kernel, every request spanning 8 shares - 7 publishers hand their
+    partials to each merging workgroup - which no smaller test reaches.  Reference: torch fp32 on the GPU, one request
+    at a time, same gather as the reference backend (torch_native_backend.py:171-186); pools checked against
+    store-then-attend bit for bit."""
+    m, ops = _mods()
+    from test_gpu_parity import _gpu_decode_reference
+    Hq, Hkv, D, ps, L, B = 8, 1, 128, 16, 32768, 32
+    lens = [L] * B
+    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens)) == 0, "the share kernel is the one measured at B = 32"
+    npages = B * (L // ps)
+    table = torch.randperm(npages, generator=torch.Generator().manual_seed(B)).to(torch.int32).view(B, L // ps).contiguous()
+    g = torch.Generator(device=DEV).manual_seed(100 + B)
+    kp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)
+    vp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)
+    qkv = (torch.randn((B, (Hq + 2 * Hkv) * D), generator=g, device=DEV) * 2).to(torch.bfloat16)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
+    loc = ops.out_cache_loc(dt, dr, dl - 1, ps)
+    kp1, vp1 = kp.clone(), vp.clone()
+    ops.kv_store(kp1, vp1, loc, k, v)
+    ref = _gpu_decode_reference(q.contiguous(), kp1, vp1, dt, list(range(B)), lens, ps, Hq)
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    for rep in range(3):                                  # the hand-off granules are lowered and raised again every launch
+        o = ops.decode_attn_planned(q, kp, vp, plan, Hq, k_new=k, v_new=v)
+        torch.cuda.synchronize()
+        assert torch.equal(kp, kp1) and torch.equal(vp, vp1), rep
+        assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL), (rep, float((o.float() - ref).abs().max()))
+    assert plan.error() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# cfg3
+# ------------------------------------------------------------------------------------------------
+def test_cfg3_full_size_prefill_then_decode():
+    """configs[2] at the size bench.py times (harness.workloads.prefill_cfg3_case): Llama-3-8B shape (32, 8, 128), 16
+    requests in 4 groups, each group's 1024-token prefix on the SAME physical pages (what RadixCache hits give), 128..512
+    new tokens each - 1216 row blocks in one launch - and then 4 decode steps of the same batch.  Prefill against torch
+    fp32 on the GPU (row j sees cached tokens 0 .. prefix + j, torch_native_backend.py:25-119); every decode step against
+    the oracle's gather-and-softmax restated in torch fp32 on the GPU, pools against store-then-attend bit for bit."""
+    m, ops = _mods()
+    from harness import workloads as W
+    from test_gpu_parity import _gpu_decode_reference, _gpu_prefill_reference
+    c = W.prefill_cfg3_case(DEV, layers=1)
+    kp, vp = c.pools[0]
+    o = ops.prefill_attn(c.q, kp, vp, c.table, c.rows, c.dseq, c.dpre, c.cu, c.ps, c.Hq, max(c.ext), max(c.seq))
+    torch.cuda.synchronize()
+    ref = _gpu_prefill_reference(c.q, kp, vp, c.table, list(range(c.B)), c.seq, c.pre, c.ps, c.Hq)
+    assert torch.isfinite(o.float()).all()
+    assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL), float((o.float() - ref).abs().max())
+    # ---- 4 decode steps: every request grows by one token per step (its last page has room, or takes a fresh page)
+    Hq, Hkv, D, ps, B = c.Hq, c.Hkv, c.D, c.ps, c.B
+    table = torch.nn.functional.pad(c.table, (0, 2))
+    next_page = int(kp.shape[0] // ps)                     # fresh pages: B more rows of pages appended to the pools
+    g = torch.Generator(device=DEV).manual_seed(4)
+    kp = torch.cat([kp, torch.randn((B * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)])
+    vp = torch.cat([vp, torch.randn((B * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)])
+    lens = list(c.seq)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rows = torch.arange(B, device=DEV)
+    for step in range(4):
+        for b in range(B):
+            if lens[b] % ps == 0:
+                assert next_page < kp.shape[0] // ps
+                table[b, lens[b] // ps] = next_page
+                next_page += 1
+            lens[b] += 1
+        dl = torch.tensor(lens, device=DEV)
+        qkv = (torch.randn((B, (Hq + 2 * Hkv) * D), generator=g, device=DEV) * 2).to(torch.bfloat16)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        loc = ops.out_cache_loc(table, rows, dl - 1, ps)
+        kp1, vp1 = kp.clone(), vp.clone()
+        ops.kv_store(kp1, vp1, loc, k, v)
+        refd = _gpu_decode_reference(q.contiguous(), kp1, vp1, table, list(range(B)), lens, ps, Hq)
+        plan = ops.decode_plan(table, rows, dl, ps, Hq, Hkv, D, sum(lens))
+        od = ops.decode_attn_planned(q, kp, vp, plan, Hq, k_new=k, v_new=v)
+        torch.cuda.synchronize()
+        assert torch.equal(kp, kp1) and torch.equal(vp, vp1), step
+        assert torch.allclose(od.float(), refd, rtol=BF16_RTOL, atol=BF16_ATOL), (step, float((od.float() - refd).abs().max()))
+        assert plan.error() == 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -416,7 +501,8 @@ def test_decode_prepare_ring_more_than_one_round():
 def test_page_table_width_is_a_hard_bound():
     """a request longer than the page table is wide must not reach the next request's row.  The planner
     refuses it (nothing allocated); the kernels, called directly with such a plan, drop the out-of-range entries and
-    mark the slots -1, which m355_kv_store skips."""
+    mark the slots M355_NO_SLOT, which the store kernels skip (-1 wrapped to the pool's LAST slot); the decode
+    plan cuts an over-long request at its row's end and leaves it out of the fused KV store."""
     m, ops = _mods()
     ps, W = 4, 3
     kv = m.KVCache(size=64 * ps, page_size=ps, head_num=1, head_dim=64, dtype=torch.bfloat16, layer_num=1, device=DEV)
@@ -442,8 +528,46 @@ def test_page_table_width_is_a_hard_bound():
     torch.cuda.synchronize()
     assert table.tolist() == [[10, 11, 12], [14, 15, 16]]
     loc = loc.cpu().numpy().reshape(2, 16)
-    assert (loc[:, 12:] == -1).all() and loc[0, :12].tolist() == list(range(40, 52)) and loc[1, :12].tolist() == list(range(56, 68))
+    NO_SLOT = ops._lib.NO_SLOT
+    assert (loc[:, 12:] == NO_SLOT).all() and loc[0, :12].tolist() == list(range(40, 52)) and loc[1, :12].tolist() == list(range(56, 68))
     lens = torch.tensor([12, 5], dtype=torch.int64, device=DEV)
     l2, p2, loc2 = ops.decode_prepare(table, torch.tensor([0, 1], device=DEV), lens, torch.tensor([99, -1], dtype=torch.int32, device=DEV), ps)
     torch.cuda.synchronize()
-    assert table.tolist() == [[10, 11, 12], [14, 15, 16]] and loc2.tolist() == [-1, 15 * ps + 1]
+    assert table.tolist() == [[10, 11, 12], [14, 15, 16]] and loc2.tolist() == [NO_SLOT, 15 * ps + 1]
+    # prepare -> kv_store with the over-wide request: every pool row keeps its contents (the marked tokens are skipped;
+    # -1 would have landed in the LAST slot, a live request's KV); same through the fused rope + store
+    S, Hkv, D = 80, 1, 64
+    kp0 = torch.randn((S, Hkv, D), device=DEV).to(torch.bfloat16)
+    vp0 = torch.randn((S, Hkv, D), device=DEV).to(torch.bfloat16)
+    kp, vp = kp0.clone(), vp0.clone()
+    src = torch.randn((2, Hkv * D), device=DEV).to(torch.bfloat16)
+    ops.kv_store(kp, vp, loc2, src, src)
+    torch.cuda.synchronize()
+    keep = torch.ones(S, dtype=torch.bool, device=DEV)
+    keep[15 * ps + 1] = False
+    assert torch.equal(kp[keep], kp0[keep]) and torch.equal(vp[keep], vp0[keep])
+    assert torch.equal(kp[15 * ps + 1], src[1].view(Hkv, D))
+    kp, vp = kp0.clone(), vp0.clone()
+    cache = torch.ones((64, D), dtype=torch.float32, device=DEV)
+    ops.rope_kv_store(torch.tensor([3, 4], device=DEV), src.clone(), src.clone(), D, cache, v=src, k_pool=kp, v_pool=vp, loc=loc2)
+    torch.cuda.synchronize()
+    assert torch.equal(kp[keep], kp0[keep]) and torch.equal(vp[keep], vp0[keep])
+    # the decode plan: request 0 claims 13 tokens in a table 3 pages (12 tokens) wide.  It is attended over its 12
+    # in-table tokens, nothing is stored for it, and request 1 (row 1, the row "behind" it) is served as usual.
+    for Hq_ in (1, 4):
+        kp, vp = kp0.clone(), vp0.clone()
+        dl = torch.tensor([13, 6], dtype=torch.int64, device=DEV)
+        rows_ = torch.tensor([0, 1], device=DEV)
+        qkv = torch.randn((2, (Hq_ + 2) * D), device=DEV).to(torch.bfloat16)
+        q, k, v = qkv.split([Hq_ * D, D, D], dim=-1)
+        plan = ops.decode_plan(table, rows_, dl, ps, Hq_, Hkv, D, 19)
+        o = ops.decode_attn_planned(q, kp, vp, plan, Hq_, k_new=k, v_new=v)
+        torch.cuda.synchronize()
+        slot1 = int(table[1, 1]) * ps + 1
+        keep = torch.ones(S, dtype=torch.bool, device=DEV)
+        keep[slot1] = False
+        assert torch.equal(kp[keep], kp0[keep]) and torch.equal(vp[keep], vp0[keep])          # request 0 stored nothing
+        assert torch.equal(kp[slot1], k[1].view(Hkv, D)) and torch.equal(vp[slot1], v[1].view(Hkv, D))
+        from test_gpu_parity import _gpu_decode_reference
+        ref = _gpu_decode_reference(q.contiguous(), kp, vp, table, [0, 1], [12, 6], ps, Hq_)
+        assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)

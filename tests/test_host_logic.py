@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r"\b(m355[a-z]*_[a-z0-9_]+)\b", out))
     assert exported == set(declared), "the product library exports exactly what include/*.h declares (no dev symbols)"
-    assert lib.m355_version() == 212
+    assert lib.m355_version() == 300
     assert b"workspace" in lib.m355_strerror(-3)
 
 

@@ -62,13 +62,26 @@ def run(layer):
 for l in range(L):
     run(l)
 torch.cuda.synchronize()
-stamps.zero_()
-torch.cuda.synchronize()
-run(0)
-torch.cuda.synchronize()
-s = stamps.cpu().numpy().astype(np.int64).reshape(nblocks, NW, 8)
 us = lambda x: x * 0.01
-t0 = s[:, :, 0][s[:, :, 0] > 0].min()
+for rep in range(int(os.environ.get("STAMP_REPS", "1"))):      # several launches: is the per-XCD pattern stable?
+    stamps.zero_()
+    torch.cuda.synchronize()
+    for l in range(L):                  # back to back, as the model runs them; the LAST layer's stamps stay
+        run(l)
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().astype(np.int64).reshape(nblocks, NW, 8)
+    t0 = s[:, :, 0][s[:, :, 0] > 0].min()
+    wg_e = (s[:, :WS, 5].max(axis=1) - t0) * 0.01
+    fin_e = (s[:, WS, 5] - t0) * 0.01
+    first = (np.where(s[:, :WS, 3] > 0, s[:, :WS, 3], 1 << 62).min(axis=1) - t0) * 0.01
+    xcc = s[:, 0, 6]
+    live = s[:, 0, 5] > 0
+    print(f"rep {rep}: span {max(wg_e.max(), fin_e.max()):.2f}  streaming end p50 {np.median(wg_e[live]):.2f} max {wg_e.max():.2f}  finishing end p50 {np.median(fin_e[fin_e > 0]):.2f} max {fin_e.max():.2f}")
+    print("   by XCC_ID  (blocks, blockIdx%8 seen, first stage landed p50, streaming end p50 / max):")
+    for x in range(8):
+        sel = live & (xcc == x)
+        if sel.any():
+            print(f"     xcc {x}: n={int(sel.sum())} slots {sorted(set((np.nonzero(sel)[0] % 8).tolist()))}  first {np.median(first[sel]):.2f}  end {np.median(wg_e[sel]):.2f} / {wg_e[sel].max():.2f}")
 st = s[:, :WS].reshape(-1, 8)
 st = st[st[:, 5] > 0]
 hp = s[:, WS]
@@ -143,6 +156,14 @@ LOOP = (s[:, :8, 4] - s[:, :8, 3]) * 0.01
 for h_ in range(8):
     sel = head == h_
     print(f"  h={h_}: {np.median(wg_end[sel]):6.2f} / {wg_end[sel].max():6.2f}   loop {np.median(LOOP[sel]):6.2f}   first {np.median(S3[sel]):5.2f}")
+if os.environ.get("TAIL_STAMPS"):
+    a = hp
+    print("TAIL (finishing wave, last segment): arrival->merged %.2f  merged->store issued %.2f  issued->acked %.2f (medians); p95 %.2f %.2f %.2f" % (
+        us(np.median(a[:, 6] - a[:, 4])), us(np.median(a[:, 7] - a[:, 6])), us(np.median(a[:, 5] - a[:, 7])),
+        us(np.percentile(a[:, 6] - a[:, 4], 95)), us(np.percentile(a[:, 7] - a[:, 6], 95)), us(np.percentile(a[:, 5] - a[:, 7], 95))))
+    lastw = (s[:, :WS, 5].max(axis=1))
+    print("  last streaming wave done -> finishing saw arrival: median %.2f p95 %.2f" % (us(np.median(hp[:, 4] - lastw)), us(np.percentile(hp[:, 4] - lastw, 95))))
+    sys.exit(0)
 late = hp[:, 3] > hp[:, 4]
 has = hp[:, 3] > 0
 print(f"hand-off complete AFTER the last arrival in {int((late & has).sum())} of {int(has.sum())} merging workgroups; "
