@@ -138,6 +138,7 @@ __device__ __forceinline__ void glds16p(const void* gsrc, uint32_t lds_dst) {
     else if constexpr (POL == 3) M355_GLDS(" sc0 sc1 nt");
     else if constexpr (POL == 4) M355_GLDS(" sc0 nt");
     else if constexpr (POL == 5) M355_GLDS(" sc1");
+    else if constexpr (POL == 6) M355_GLDS(" sc0 sc1");
     else M355_GLDS("");
 #undef M355_GLDS
 }

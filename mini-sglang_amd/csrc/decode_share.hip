@@ -201,10 +201,19 @@ __device__ __forceinline__ float ld_agent(const float* p) {          // global_l
 __device__ __forceinline__ void st_agent(float* p, float v) {        // global_store_dword sc1: write-through
     __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st_agent16(u32x4* p, u32x4 v) {      // global_store_dwordx4 sc1: ONE write-through store of a granule
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ int32_t lds_peek(const int32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+#ifndef M355_CROSS_POL
+#define M355_CROSS_POL 5          // cache policy of the hand-off's LDS-DMA loads (common.h glds16p): sc1, agent scope
+#endif
+#ifndef M355_CROSS_EVERY
+#define M355_CROSS_EVERY 6        // polls (~0.2 us each) between two requests for a publisher's granules
+#endif
 constexpr int kPollLimit = 1 << 22;             // bounded waits (each round sleeps): ~seconds, then kHError is raised
 
 template <int D, int G>
@@ -273,9 +282,9 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
         const int32_t* stg = p.plan + p.off_stg;
         const int S1 = SO + NS;
         constexpr int VEC = S::VEC;
-        constexpr int NG = VEC + 2;                                  // granules per lane: its VEC elements of O, m and l of its q head
-        // hand-off area of (kv head h, share i): NG x 64 granules {fp32 value, tag}, granule k of lane L at (k*64 + L)
-        unsigned long long* const gran = reinterpret_cast<unsigned long long*>(p.plan + p.off_gran) + (int64_t)h * p.nb * (NG * 64);
+        constexpr int NG = share_granules(D, G);                     // 16-byte granules per lane: {3 of its VEC + 2 values (O, m, l), tag}
+        // hand-off area of (kv head h, share i): NG x 64 granules, granule k of lane L at (k*64 + L)
+        u32x4* const gran = reinterpret_cast<u32x4*>(p.plan + p.off_gran) + (int64_t)h * p.nb * (NG * 64);
         const int e0 = lane * VEC;                                   // first of this lane's elements of O[G][D]
         const int g = e0 / D, d0 = e0 - g * D;
         // hand-off state: only the share's LAST segment can end a request that began in an earlier share
@@ -288,47 +297,56 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
 #pragma unroll
         for (int x = 0; x < VEC; ++x) cacc[x] = 0.f;
         bool failed = false;
-        // The hand-off runs BESIDE the segment loop and never makes it wait: a publisher's partial travels as 8-byte
-        // granules {value, tag}, each written by ONE write-through store, so there is no flag and no ordering to wait
-        // for; this wave loads the next publisher's granules in one call of cross_step and looks at them kCrossLag calls
-        // later (a wave stalled on a global access of a streaming CU would not see its own streaming waves arrive).
+        // The hand-off runs BESIDE the segment loop and never makes it wait.  A publisher's partial travels as 16-byte
+        // granules {3 values, tag = publisher's share + 1}, each written by ONE write-through store, so there is no flag and
+        // no ordering to wait for.  This wave asks for the next publisher's granules by LDS-DMA into a staging area of its
+        // own every kCrossEvery polls and LOOKS at the staging area (LDS reads) on every poll: nothing here ever waits for
+        // memory.  (Loaded into registers, the granules were loop-carried values: the register copies hipcc places on the
+        // loop's edges each waited for the loads in flight - ~2 us per segment on a streaming CU, during which arrived
+        // segments went unmerged and hand-offs unnoticed: 57 of 248 merging workgroups on configs[1] ended on it.)
         // All tags raised: the partial is folded into (cm, cl, cacc) and its granules are lowered again for the next
-        // launch.  Measured on configs[1] (one box, stamps): with a lag of 20 polls a load -> look cycle takes ~2.5 us
-        // and 112 of 248 merging workgroups finished their hand-off AFTER their last stage (+1.4 us); lag 6: 21, lag 2:
-        // 10, tail p95 2.4 -> 1.5 us - and the same launch time, which the slowest streaming waves set.
-#ifndef M355_CROSS_LAG
-#define M355_CROSS_LAG 4
-#endif
-        constexpr int kCrossLag = M355_CROSS_LAG;
-        int cstate = 0, cage = 0;
-        unsigned long long cg[NG];
+        // launch.  A DMA that lands after that carries the old publisher's tag and is ignored.
+        constexpr int kCrossEvery = M355_CROSS_EVERY;
+        uint8_t* const stage = reinterpret_cast<uint8_t*>(ctl) + 64;
+        const uint32_t stage0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
 #pragma unroll
-        for (int x = 0; x < NG; ++x) cg[x] = 0ull;
-        auto cross_step = [&](const bool hurry, const bool look = true) {
-            unsigned long long* src = gran + (int64_t)cross_next * (NG * 64) + lane;
-            if (cstate == 0) {
+        for (int k = 0; k < NG; ++k) *reinterpret_cast<u32x4*>(stage + k * 1024 + 16 * lane) = u32x4{0u, 0u, 0u, 0u};
+        int cage = kCrossEvery;
+        auto cross_step = [&]() {
+            const u32x4* src = gran + (int64_t)cross_next * (NG * 64) + lane;
+            if (++cage >= kCrossEvery) {                             // ask (again): served past this CU's L1 (sc1)
+                cage = 0;
 #pragma unroll
-                for (int x = 0; x < NG; ++x) cg[x] = __hip_atomic_load(src + x * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cstate = 1; cage = 0;
-                return;
+                for (int k = 0; k < NG; ++k) glds16p<M355_CROSS_POL>(src + k * 64, stage0 + k * 1024);
             }
-            if (!hurry && (++cage < kCrossLag || !look)) return;
+            const uint32_t want = (uint32_t)cross_next + 1u;
             bool mine = true;
 #pragma unroll
-            for (int x = 0; x < NG; ++x) mine = mine && (uint32_t)(cg[x] >> 32) == 1u;
-            cstate = 0;
-            if (!__all(mine)) return;                                // not (all) there yet: look again
+            for (int k = 0; k < NG; ++k)
+                mine = mine && __hip_atomic_load(reinterpret_cast<const uint32_t*>(stage + k * 1024 + 16 * lane + 12), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP) == want;
+            if (!__all(mine)) return;                                // not (all) there yet: look again next time
+            __builtin_amdgcn_s_sleep(1);                             // (a granule lands as one LDS write; this covers one that does not)
+            asm volatile("" ::: "memory");
+            float vals[3 * NG];
+#pragma unroll
+            for (int k = 0; k < NG; ++k)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    vals[3 * k + j] = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(stage + k * 1024 + 16 * lane + 4 * j),
+                                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             shstamp<STAMP>(p, wave, 6);
-            const float pm = __builtin_bit_cast(float, (uint32_t)cg[VEC]), pl = __builtin_bit_cast(float, (uint32_t)cg[VEC + 1]);
+            const float pm = vals[VEC], pl = vals[VEC + 1];
             const float nm = fmaxf(cm, pm);
             const float wa = exp2_fast(cm - nm), wb = exp2_fast(pm - nm);
             cl = cl * wa + pl * wb;
 #pragma unroll
-            for (int x = 0; x < VEC; ++x) cacc[x] = cacc[x] * wa + __builtin_bit_cast(float, (uint32_t)cg[x]) * wb;
+            for (int x = 0; x < VEC; ++x) cacc[x] = cacc[x] * wa + vals[x] * wb;
             cm = nm;
 #pragma unroll
-            for (int x = 0; x < NG; ++x) __hip_atomic_store(src + x * 64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < NG; ++k) st_agent16(const_cast<u32x4*>(src) + k * 64, u32x4{0u, 0u, 0u, 0u});
             --cross_next; --cross_left;
+            cage = kCrossEvery;                                      // the next publisher's granules are asked for at once
             if (cross_left == 0) shstamp<STAMP>(p, wave, 3);
         };
         // the segments, last request first; their stage ranges come from stg, 64 requests per load
@@ -352,11 +370,8 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             base += nst;
             int32_t* const arrived = ctl + 2 + ord % p.nslot;
             int spins = 0;
-            int seen;
-            while ((seen = lds_peek(arrived)) < e) {                 // the segment's waves; meanwhile, the hand-off - but only
-                // while none of them has arrived: looking at granules means waiting for their loads (microseconds on a
-                // streaming CU), and the first arrival says the others are about to follow
-                if (cross_left > 0) cross_step(false, seen == 0);     // (asking for granules never waits; looking at them does)
+            while (lds_peek(arrived) < e) {                          // the segment's waves; meanwhile, the hand-off
+                if (cross_left > 0) cross_step();
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > kPollLimit) { failed = true; break; }
             }
@@ -405,13 +420,17 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                 __hip_atomic_store(ctl + 1, ord + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (kind == kSegPublish) {                               // every lane: its elements, and m / l of its q head
-                unsigned long long* dst = gran + (int64_t)share * (NG * 64) + lane;
-                const unsigned long long tag = 1ull << 32;
+                u32x4* dst = gran + (int64_t)share * (NG * 64) + lane;
+                float vals[3 * NG];
 #pragma unroll
-                for (int x = 0; x < VEC; ++x)
-                    __hip_atomic_store(dst + x * 64, tag | __builtin_bit_cast(uint32_t, acc[x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + VEC * 64, tag | __builtin_bit_cast(uint32_t, gm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + (VEC + 1) * 64, tag | __builtin_bit_cast(uint32_t, den), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int x = 0; x < 3 * NG; ++x) vals[x] = 0.f;
+#pragma unroll
+                for (int x = 0; x < VEC; ++x) vals[x] = acc[x];
+                vals[VEC] = gm; vals[VEC + 1] = den;
+#pragma unroll
+                for (int k = 0; k < NG; ++k)
+                    st_agent16(dst + k * 64, u32x4{__builtin_bit_cast(uint32_t, vals[3 * k]), __builtin_bit_cast(uint32_t, vals[3 * k + 1]),
+                                                   __builtin_bit_cast(uint32_t, vals[3 * k + 2]), (uint32_t)share + 1u});
                 shstamp<STAMP>(p, wave, 7);
                 ++ord;
                 continue;
@@ -419,8 +438,8 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             if (kind == kSegMerge) {
                 int spins2 = 0;
                 while (cross_left > 0 && !failed) {                 // whatever of the hand-off is still open: now it is waited for
-                    cross_step(true);
-                    if (cstate == 0 && cross_left > 0) __builtin_amdgcn_s_sleep(8);
+                    cross_step();
+                    if (cross_left > 0) __builtin_amdgcn_s_sleep(2);
                     if (++spins2 > kPollLimit) failed = true;
                 }
                 const float nm = fmaxf(cm, gm);
@@ -453,7 +472,8 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             ++ord;
         }
         if (failed && lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(p.plan) + kHError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); shstamp<STAMP>(p, wave, 5); }
+        wait_vmcnt<0>();                                             // (no LDS-DMA may outlive its wave; none is left unless the hand-off came late)
+        if constexpr (STAMP) shstamp<STAMP>(p, wave, 5);
         return;
     }
 
@@ -677,7 +697,7 @@ ShareShape share_shape(int Hkv, int D, int G) {
     constexpr int kLds = 160 * 1024;
     for (int W = share_max_waves(D); W >= 1; --W) {
         for (int ns = 4; ns >= 1; --ns) {
-            const int lds = W * waveb + ns * W * pw * 4 + 64;
+            const int lds = W * waveb + ns * W * pw * 4 + 64 + share_granules(D, G) * 1024;   // ... + ctl + the hand-off staging area
             if (lds <= kLds) {
                 r.W = W; r.nslot = ns; r.lds_bytes = lds; r.ok = true;
                 r.nb = cu_count() / Hkv;

@@ -23,8 +23,9 @@ constexpr int kShareCumLds = 4096;              // requests whose prefix sums th
 // header words
 constexpr int kHTotal = 0, kHShareStages = 1, kHB = 2, kHShares = 3, kHWaves = 4, kHStages = 5, kHError = M355_PLAN_ERROR_WORD, kHShareRem = 7;
 
-// hand-off granules per (kv head, share): one fp32 partial O[G][D] + m, l per lane, 8 bytes {value, tag} each
-__host__ __device__ inline int64_t share_gran_words(int D, int G) { return (int64_t)((G * D / 64 > 0 ? G * D / 64 : 1) + 2) * 64 * 2; }
+// hand-off granules per (kv head, share): one fp32 partial O[G][D] + m, l per lane, as 16-byte granules {3 values, tag}
+__host__ __device__ constexpr int share_granules(int D, int G) { return ((G * D / 64 > 0 ? G * D / 64 : 1) + 2 + 2) / 3; }
+__host__ __device__ inline int64_t share_gran_words(int D, int G) { return (int64_t)share_granules(D, G) * 64 * 4; }
 
 // plan buffer (int32 words): hdr | cum[B+1] | stg[B+1] | nz[B+1] | share[nb][kShareW] | gran[Hkv*nb][...] | rec[nb][qcap][kRecW]
 // Share i's records start at a place that depends on i alone (i * qcap), so a wave asks for its first records with its

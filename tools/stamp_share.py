@@ -156,6 +156,8 @@ LOOP = (s[:, :8, 4] - s[:, :8, 3]) * 0.01
 for h_ in range(8):
     sel = head == h_
     print(f"  h={h_}: {np.median(wg_end[sel]):6.2f} / {wg_end[sel].max():6.2f}   loop {np.median(LOOP[sel]):6.2f}   first {np.median(S3[sel]):5.2f}")
+if os.environ.get("STAMP_DUMP"):
+    np.save(os.environ["STAMP_DUMP"], s - t0)
 if os.environ.get("TAIL_STAMPS"):
     a = hp
     print("TAIL (finishing wave, last segment): arrival->merged %.2f  merged->store issued %.2f  issued->acked %.2f (medians); p95 %.2f %.2f %.2f" % (
