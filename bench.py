@@ -216,6 +216,13 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
     if tp == 1:
         # the 8B head shape on the same batch as the headline ((32, 8, 128))
         out["decode_8b_shape"] = guarded(W.decode_shape_report, dev, 32, 8, 128, W.cfg2_lengths(1), 16)
+        # the headline batch on the REFERENCE's contiguous [S, Hkv, D] pools (memory/kvcache.py:24-35; what INTEGRATION.md's
+        # one-line edit runs on): mi355_attn.KVCache pads every token row by 128 bytes (12.5 % of the pool on this shape)
+        out["decode_contiguous_pool"] = guarded(W.decode_shape_report, dev, MODEL["Hq"], MODEL["Hkv"], MODEL["D"], W.cfg2_lengths(1), 16,
+                                                row_pad=0)
+        if isinstance(out["decode_contiguous_pool"], dict):
+            out["decode_contiguous_pool"]["note"] = ("same batch and kernel as the headline, KVCache(row_pad=0): the reference's pool layout; "
+                                                     "the headline's padded rows cost 12.5 % more HBM per cached token on this shape")
     if tp in (1, 8):
         # cfg5: what ONE rank of Llama-3-70B at TP=8 streams - (8, 1, 128), every request 32 768 tokens (16 of the 80 layers)
         out["decode_cfg5_per_rank"] = {
@@ -225,6 +232,9 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
     # cfg3 / cfg4: Llama-3-8B prefill over shared cached prefixes, this rank's heads
     note(rank, "prefill cfg3")
     out["prefill_cfg3" if tp == 1 else "prefill_cfg3_per_rank"] = guarded(prefill_cfg3, dev, tp)
+    if tp == 1:
+        note(rank, "cfg3 end to end through the radix tree")
+        out["cfg3_flow"] = {"native_tree": guarded(W.cfg3_flow, dev, True), "python_tree": guarded(W.cfg3_flow, dev, False)}
     note(rank, "fused o_proj probe (child processes)" if tp > 1 else "bench_one_batch")
     fused_ok = tp > 1 and fused_probe(dev, tp)
     if tp > 1:
@@ -281,6 +291,12 @@ def fused_probe_child() -> int:
         for _ in range(3):                                  # epochs, both buffer halves
             y = f(x, w)
         torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()                            # an exchange is ~20 us when the ranks' kernels run side by side; a
+        for _ in range(4):                                  # device that time-slices the processes shows its quantum here
+            y = f(x, w)
+        torch.cuda.synchronize()
+        per_call_ms = (time.perf_counter() - t0) * 1e3 / 4
         want = torch.nn.functional.linear(x, w).float().cpu()
         dist.all_reduce(want)
         err = float((y.float().cpu() - want).abs().max())
@@ -292,6 +308,7 @@ def fused_probe_child() -> int:
     if gave_up or not err < 0.05:
         print(f"FUSED_PROBE_FAILED rank {rank}: max diff {err}, wait gave up {gave_up}", flush=True)
         return 1
+    print(f"FUSED_PROBE_MS rank {rank}: {per_call_ms:.3f}", flush=True)
     print("FUSED_PROBE_OK", flush=True)
     return 0
 

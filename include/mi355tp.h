@@ -50,10 +50,12 @@ typedef struct M355OprojRank {
     int32_t reserved;
 } M355OprojRank;
 
-/* Uncached, zero-filled device memory on the current device / its release.  Set-up time only.
- * Keep these allocations for the life of the process (mi355_attn.tp pools them): on ROCm 7.2 / gfx950 a normal allocation
- * that later lands on the address range of a FREED uncached one was seen read through stale 4 KiB translations (whole
- * pages of a fresh tensor holding old data) - m355_comm_free is for process tear-down. */
+/* Uncached, zero-filled device memory on the current device / its release.  Set-up time only (both synchronise the device).
+ * m355_comm_free does NOT hand the memory back to the driver: the block goes to a pool inside the library and the next
+ * m355_comm_alloc of the same size on the same device gets it back, zeroed.  (On ROCm 7.2 / gfx950 a normal allocation
+ * that later lands on the address range of a hipFree'd uncached one was seen read through stale 4 KiB translations - whole
+ * pages of a fresh tensor holding old data - so uncached memory stays with the library until the process ends.)
+ * m355_comm_free of a pointer m355_comm_alloc did not return: M355_ERR_INVALID_ARG. */
 int m355_comm_alloc(int64_t bytes, void **ptr);
 int m355_comm_free(void *ptr);
 /* Zero an allocation again (set-up time; synchronises): for a caller that keeps buffers and re-uses them. */
@@ -71,6 +73,14 @@ int64_t m355_oproj_flag_bytes(int32_t world, int32_t T_cap, int32_t N);
  * `ranks` (HOST memory) holds n_ranks entries: 1 in production (this process's rank); n_ranks == world runs every rank
  * of a world whose buffers all live on THIS device in one launch (how the single-GPU parity test drives it).
  * T <= T_cap rows; N % 64 == 0; K % 32 == 0; bf16 or f16.  error: device int32 raised to 1 when a wait gave up, or NULL.
+ * A wait that gives up (a peer did not arrive within ~1 s of polls) also writes NaN into that tile's rows of `out`, so the
+ * result cannot pass for a sum; from then on the instance is OUT OF STEP with its peers and unusable - a late push may
+ * land in a half that a faster rank has re-used - until every rank has zeroed its receive buffer, flag array and
+ * epoch_state again (m355_comm_zero) and the host epoch restarts.  Check *error wherever the caller synchronises anyway.
+ * T == 0 launches nothing and is NOT a call: with a host-counted epoch do not advance it (the two buffer halves rely on
+ * a completed call of the other parity in between).
+ * n_ranks == world > 1 (all ranks in one launch on one device, the parity test's form) needs every workgroup of the
+ * launch resident at once: ceil(T/16) * N/64 * world beyond what the device holds is refused with M355_ERR_INVALID_ARG.
  * The call's epoch is `epoch` (counted by the host: 1, 2, 3, ...) when epoch_state is NULL.  Otherwise epoch_state is
  * device memory of m355_oproj_flag_bytes(world, T_cap, N) bytes, zeroed once at set-up, where the launch keeps a call
  * count per (rank, tile) and advances it itself: the SAME launch (same arguments) can then be replayed from a captured HIP

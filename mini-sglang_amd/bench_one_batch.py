@@ -157,10 +157,15 @@ class GraphedDecode:
         self.step += 1
 
     def next(self):
-        """One more decode step (host mirrors + one graph launch)."""
+        """One more decode step (host mirrors + one graph launch).  Nothing in a replayed step looks at the fused
+        epilogue's error word, so every 8 steps (every step at first) an asynchronous copy of it is started and the previous
+        one examined."""
         self.batch.advance_host_for_decode()
         self.graph.replay()
         self.taken += 1
+        fused = getattr(self.runner.model, "fused", None)
+        if fused is not None and (self.taken % 8 == 0 or self.taken < 8):
+            fused.poll_error()
 
     def tokens(self) -> torch.Tensor:
         return self.out[:, : self.taken]
@@ -168,6 +173,7 @@ class GraphedDecode:
     def release(self) -> None:
         """Drop the captured graph; the backend may size its buffers freely again."""
         torch.cuda.synchronize()
+        self.runner.attn_backend.check()                 # (a sync was just paid: the decode plan's give-up word)
         self.graph = None
         self.runner.attn_backend.buffers_pinned = False
         self.runner.attn_backend.decode_capacity_hint = 0

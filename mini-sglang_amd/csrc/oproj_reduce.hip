@@ -14,6 +14,12 @@
 // Weight traffic dominates (N x K elements per rank, read once); x is re-read by the N/64 workgroups of a row block from L2.
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 #include "../../include/mi355tp.h"
 
@@ -50,6 +56,8 @@ template <bool F16>
 __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 4))) void oproj_allreduce_kernel(const OprojParams p) {
     __shared__ __attribute__((aligned(16))) float red[4][16][68];
     __shared__ uint32_t epoch_s;
+    __shared__ int gave_up_s;
+    if (threadIdx.x == 0) gave_up_s = 0;                 // (published by the barrier behind the GEMM)
     const M355OprojRank& R = p.r[blockIdx.z];
     // the call's epoch: the host's count, or - so that ONE captured launch can be replayed - a count per (rank, tile) in
     // device memory that the tile's own workgroup reads and advances (wave 4, below): no other workgroup of any launch
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
             __builtin_amdgcn_s_sleep(4);
             if (++spins > kOprojPollLimit) {
                 if (p.error) __hip_atomic_store(p.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                gave_up_s = 1;                           // the tile's rows come out as NaN: a sum without every rank is not a result
                 break;
             }
         }
@@ -158,7 +167,12 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[2 * e] += unpack16_lo<F16>(w[e]); s[2 * e + 1] += unpack16_hi<F16>(w[e]); }
         }
-        const u32x4 o = {pack16<F16>(s[0], s[1]), pack16<F16>(s[2], s[3]), pack16<F16>(s[4], s[5]), pack16<F16>(s[6], s[7])};
+        u32x4 o = {pack16<F16>(s[0], s[1]), pack16<F16>(s[2], s[3]), pack16<F16>(s[4], s[5]), pack16<F16>(s[6], s[7])};
+        // A peer never arrived (the wait above gave up): whatever sits in its slot is not its tile.  NaN the rows instead of
+        // handing plausible numbers on - the model's next argmax / comparison then cannot look right - and leave *error set.
+        // After that the instance is out of step with its peers for good (a late push can land in a half that a faster rank
+        // has re-used): buffers, flags and epoch_state have to be zeroed again by every rank before the next call.
+        if (gave_up_s) { const uint32_t nan2 = F16 ? 0x7e007e00u : 0x7fc07fc0u; o = u32x4{nan2, nan2, nan2, nan2}; }
         *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(R.out) + (int64_t)(row0 + row) * R.out_row_stride + col0 + c8) = o;
     }
 }
@@ -167,11 +181,46 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 
 using namespace m355;
 
+// Freed allocations are kept, per device and size, for the next m355_comm_alloc of that size: on ROCm 7.2 / gfx950 a normal
+// allocation that later lands on the address range of a hipFree'd UNCACHED one was seen read through stale 4 KiB
+// translations (whole pages of a fresh tensor holding old data), so uncached memory is never handed back to the driver.
+namespace {
+struct CommPool {
+    std::mutex mu;
+    std::unordered_map<void*, std::pair<int, int64_t>> live;                   // ptr -> (device, bytes)
+    std::map<std::pair<int, int64_t>, std::vector<void*>> spare;              // (device, bytes) -> freed blocks
+};
+CommPool& comm_pool() { static CommPool p; return p; }
+}  // namespace
+
 extern "C" int m355_comm_alloc(int64_t bytes, void** ptr) {
     if (!ptr || bytes <= 0) return M355_ERR_INVALID_ARG;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return M355_ERR_LAUNCH; }
+    {
+        CommPool& cp = comm_pool();
+        std::lock_guard<std::mutex> lock(cp.mu);
+        auto it = cp.spare.find({dev, bytes});
+        if (it != cp.spare.end() && !it->second.empty()) {
+            void* q = it->second.back();
+            if (hipDeviceSynchronize() != hipSuccess || hipMemset(q, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                (void)hipGetLastError();
+                return M355_ERR_LAUNCH;
+            }
+            it->second.pop_back();
+            cp.live[q] = {dev, bytes};
+            *ptr = q;
+            return M355_OK;
+        }
+    }
     void* p = nullptr;
     if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess || !p) { (void)hipGetLastError(); return M355_ERR_LAUNCH; }
     if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return M355_ERR_LAUNCH; }
+    {
+        CommPool& cp = comm_pool();
+        std::lock_guard<std::mutex> lock(cp.mu);
+        cp.live[p] = {dev, bytes};
+    }
     *ptr = p;
     return M355_OK;
 }
@@ -180,9 +229,14 @@ extern "C" int m355_comm_zero(void* ptr, int64_t bytes) {
     if (hipMemset(ptr, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return M355_ERR_LAUNCH; }
     return M355_OK;
 }
-extern "C" int m355_comm_free(void* ptr) {
+extern "C" int m355_comm_free(void* ptr) {             // (back to the pool, see above; never hipFree)
     if (!ptr) return M355_OK;
-    if (hipFree(ptr) != hipSuccess) { (void)hipGetLastError(); return M355_ERR_LAUNCH; }
+    CommPool& cp = comm_pool();
+    std::lock_guard<std::mutex> lock(cp.mu);
+    auto it = cp.live.find(ptr);
+    if (it == cp.live.end()) return M355_ERR_INVALID_ARG;       // not one of ours (or freed twice)
+    cp.spare[it->second].push_back(ptr);
+    cp.live.erase(it);
     return M355_OK;
 }
 extern "C" int m355_comm_export(void* ptr, void* handle64) {
@@ -224,6 +278,15 @@ extern "C" int m355_oproj_allreduce(const M355OprojRank* ranks, int32_t n_ranks,
     if (N % 64 || K % 32) return M355_ERR_UNSUPPORTED;
     if (dtype != M355_DTYPE_BF16 && dtype != M355_DTYPE_F16) return M355_ERR_UNSUPPORTED;
     if ((int64_t)((T + 15) / 16) * (N / 64) * n_ranks > 65535ll * 16) return M355_ERR_INVALID_ARG;
+    if (n_ranks == world && world > 1) {
+        // every rank of the world in ONE launch on this device: a tile waits for the same tile of the other ranks, so all
+        // workgroups of the launch have to be resident together or the low ranks' tiles wait for ranks that cannot start
+        int per_cu = 0;
+        const void* fn = dtype == M355_DTYPE_F16 ? reinterpret_cast<const void*>(&oproj_allreduce_kernel<true>)
+                                                 : reinterpret_cast<const void*>(&oproj_allreduce_kernel<false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 320, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+        if ((int64_t)((T + 15) / 16) * (N / 64) * n_ranks > (int64_t)cu_count() * per_cu) return M355_ERR_INVALID_ARG;
+    }
     OprojParams p;
     memset(&p, 0, sizeof p);
     for (int i = 0; i < n_ranks; ++i) {

@@ -20,7 +20,6 @@
 #include <stdlib.h>
 
 #include "prefill_common.h"
-#include "paged_rows.h"
 
 namespace m355 {
 
@@ -582,7 +581,7 @@ static int ilog2_exact_p(int32_t x) {
     return s;
 }
 
-static int prefill_mode() {      // dev build cross-check hook: 1 = row-parallel (VALU) path, 2 = one-wave-per-tile MFMA kernel
+static int prefill_mode() {      // dev build cross-check hook: 2 = the older one-wave-per-tile MFMA kernel
     static const int v = dev_env_int("M355_PREFILL_MODE", 0);
     return v;
 }
@@ -741,12 +740,6 @@ extern "C" int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D
         const int sp = prefill_splits(T, Hq, max_seq_len_hint);
         return sp > 1 ? (int64_t)T * Hq * sp * (D + 4) * (int64_t)sizeof(float) : 0;
     }
-#ifdef M355_DEV
-    if (prefill_mode() == 1) {
-        const int64_t splits = (max_seq_len_hint + kRowsMaxChunk - 1) / kRowsMaxChunk;
-        return splits <= 1 ? 0 : (int64_t)T * Hq * splits * (D + 2) * (int64_t)sizeof(float);
-    }
-#endif
     return 0;
 }
 
@@ -762,12 +755,6 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
         return M355_ERR_INVALID_ARG;
     if (pool_row_stride == 0) pool_row_stride = (int64_t)Hkv * D;
     if (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8) return M355_ERR_INVALID_ARG;
-#ifdef M355_DEV
-    if (prefill_mode() == 1)        // row-parallel path: every packed query row handled like a decode query
-        return paged_rows_attn(q, q_row_stride, k_pool, v_pool, pool_row_stride, page_table, pt_row_stride, page_table_ids, nullptr, cu_q,
-                               prefix_lens, B, out, o_row_stride, T, Hq, Hkv, D, page_size, scale, max_seq_len_hint,
-                               kRowsMaxChunk, workspace, workspace_bytes, dtype, (hipStream_t)stream);
-#endif
     const bool f16 = dtype == M355_DTYPE_F16;          // IEEE half: the workgroup kernel only
     if (dtype != M355_DTYPE_BF16 && !(f16 && prefill_mode() == 0)) return M355_ERR_UNSUPPORTED;
     if (D != 64 && D != 128) return M355_ERR_UNSUPPORTED;

@@ -153,4 +153,9 @@ class HarnessRunner:
         self.attn_backend.init_forward_metadata(batch)                                      # model_runner.py:194-195
         batch.attn_backend = self.attn_backend
         logits = self.model.forward(batch)
+        fused = getattr(self.model, "fused", None)
+        if fused is not None and not torch.cuda.is_current_stream_capturing():
+            # the fused row-parallel launches' give-up word: an asynchronous copy is started here and the PREVIOUS forward's is
+            # examined - no sync; a peer that never arrived (that forward's rows are NaN) raises within a step or two
+            fused.poll_error()
         return logits, torch.argmax(logits, dim=-1)                                         # temperature 0 (:201-205)

@@ -37,13 +37,13 @@ def kv_store_bytes_per_layer(T: int, Hkv: int, D: int) -> int:
 
 
 def decode_case(dev: str, Hq: int, Hkv: int, D: int, lens: Sequence[int], layers: int, ps: int = 16, room: int = 64,
-                seed: int = 1234, device_free_list: bool = True) -> SimpleNamespace:
+                seed: int = 1234, device_free_list: bool = True, row_pad: Optional[int] = None) -> SimpleNamespace:
     """A batch with `lens` cached tokens per request in `layers` distinct, randomly filled KV pools, physical pages
     handed out in shuffled order, ready for prepare_for_decode (`room` further tokens per request fit)."""
     B = len(lens)
     pages = sum(-(-(l + room) // ps) for l in lens) + 8
     kv = m.KVCache(size=pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=layers,
-                   device=dev, device_free_list=device_free_list)
+                   device=dev, device_free_list=device_free_list, row_pad=row_pad)
     pm = m.PageManager(page_size=ps, max_req_num=B, max_context_len=(max(lens) + room) // ps * ps + 2 * ps, device=dev)
     kv.set_free_pages(torch.randperm(pages, generator=torch.Generator().manual_seed(0)).tolist())
     gg = torch.Generator(device=dev).manual_seed(seed)
@@ -115,9 +115,9 @@ def time_decode_launches(c: SimpleNamespace, reps: int = 20, fused: bool = True)
 
 
 def decode_shape_report(dev: str, Hq: int, Hkv: int, D: int, lens: Sequence[int], layers: int, reps: int = 20,
-                        ps: int = 16) -> dict:
+                        ps: int = 16, row_pad: Optional[int] = None) -> dict:
     """Launch-level roofline of decode attention for one head shape / batch (a side measurement of bench.py)."""
-    c = decode_case(dev, Hq, Hkv, D, lens, layers, ps=ps, room=8)
+    c = decode_case(dev, Hq, Hkv, D, lens, layers, ps=ps, room=8, row_pad=row_pad)
     for _ in range(2):
         decode_step(c)
     us, nbytes = time_decode_launches(c, reps)
@@ -181,3 +181,104 @@ def time_prefill(c: SimpleNamespace, reps: int = 10) -> dict:
             "kernel": "m355::prefill_wg_kernel", "us_per_layer": round(us, 2), "gflop_per_layer": round(flops / 1e9, 2),
             "tflops": round(flops / us / 1e6, 1), "frac_of_mfma_peak": round(flops / us / 1e6 / MFMA_PEAK_TFLOPS, 4),
             "prefill_tok_per_s_per_layer": round(c.T / us * 1e6, 0), "min_bytes_MB": round(byts / 1e6, 2)}
+
+
+def cfg3_flow(dev: str, native_tree: bool = True, Hq: int = 32, Hkv: int = 8, D: int = 128, ps: int = 16, layers: int = 8,
+              groups: int = 4, per_group: int = 4, prefix: int = 1024, suffix=(128, 512), decode_steps: int = 64) -> dict:
+    """SURVEY §8d cfg3 END TO END, the way the scheduler drives it (engine/scheduler.py:295-297, 415-436;
+    engine/batch.py:128-132): the groups' shared prefixes are already in the radix tree (one earlier request per group put
+    them there), then the 16 requests are served as ONE batch:
+
+        Req.init_next_round_input(tree)   match_prefix -> prefix_ppns            (host; native C++ tree or the Python tree)
+        Batch.prepare_for_prefill()       rows, pages, positions, slots         (host plan + one HIP launch)
+        per layer: KV store + prefill attention over the shared physical pages  (m355_kv_store + m355_prefill_attn)
+        tree.cache_unfinished_req(req)    the new pages go into the tree        (host)
+        `decode_steps` x [prepare_for_decode + per layer fused KV store + decode attention]
+
+    Host times are wall clock around the host calls (the GPU is idle or busy elsewhere); GPU times are HIP events."""
+    import time
+
+    from mi355_attn.radix_cache import NativeRadixCache, PagedRadixCache
+    random.seed(0)
+    B = groups * per_group
+    ext = [random.randint(*suffix) for _ in range(B)]
+    rng = random.Random(1)
+    prefixes = [[rng.randrange(32000) for _ in range(prefix)] for _ in range(groups)]
+    prompts = [prefixes[i // per_group] + [rng.randrange(32000) for _ in range(ext[i])] for i in range(B)]
+    pages = groups * (prefix // ps + 2) + sum(-(-(len(p) + decode_steps + ps) // ps) for p in prompts) + 16
+    kv = m.KVCache(size=pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.bfloat16, layer_num=layers, device=dev,
+                   device_free_list=True)
+    kv.set_free_pages(torch.randperm(pages, generator=torch.Generator().manual_seed(0)).tolist())
+    pm = m.PageManager(page_size=ps, max_req_num=B + groups, max_context_len=prefix + suffix[1] + decode_steps + 2 * ps, device=dev)
+    tree = (NativeRadixCache if native_tree else PagedRadixCache)(pm, kv)
+    backend = m.MI355AttnBackend(SimpleNamespace(device=dev, page_size=ps, kvcache=kv, page_manager=pm))
+    attn = [m.Attention(i, Hq, Hkv, D) for i in range(layers)]
+    gg = torch.Generator(device=dev).manual_seed(7)
+
+    def forward(batch, T):
+        qkv = torch.randn((T, (Hq + 2 * Hkv) * D), generator=gg, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        backend.init_forward_metadata(batch)
+        batch.attn_backend = backend
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for layer in attn:
+            layer(q, k, v, batch)
+        e1.record()
+        return e0, e1
+
+    # ---- earlier traffic: one request per group leaves its prefix in the tree (its pages stay cached when it finishes)
+    for gi in range(groups):
+        r = m.Req(1000 + gi, list(prefixes[gi]) + [31999], m.SamplingParams(max_new_tokens=1))
+        r.init_next_round_input(tree)
+        tree.inc_lock_ref(r.last_node)                       # as the scheduler does when it admits a request (scheduler.py:300-306)
+        b0 = m.Batch([r], pm, kv, tree_cache=tree, device=dev)
+        b0.prepare_for_prefill()
+        forward(b0, len(r.fill_ids))
+        r.output_ids.append(1)
+        tree.cache_finished_req(r)
+    torch.cuda.synchronize()
+    # ---- the 16 requests, one batch
+    reqs = [m.Req(i, list(p), m.SamplingParams(max_new_tokens=decode_steps + 1)) for i, p in enumerate(prompts)]
+    t0 = time.perf_counter()
+    for r in reqs:
+        r.init_next_round_input(tree)
+        tree.inc_lock_ref(r.last_node)
+    t_match = time.perf_counter() - t0
+    hit = [len(r.prefix_ppns) * ps for r in reqs]
+    batch = m.Batch(reqs, pm, kv, tree_cache=tree, device=dev)
+    t0 = time.perf_counter()
+    batch.prepare_for_prefill()
+    t_prep = time.perf_counter() - t0
+    T = sum(len(r.fill_ids) - h for r, h in zip(reqs, hit))
+    e0, e1 = forward(batch, T)
+    torch.cuda.synchronize()
+    prefill_us = e0.elapsed_time(e1) * 1e3
+    t0 = time.perf_counter()
+    for r in reqs:
+        r.output_ids.append(1)
+        tree.cache_unfinished_req(r)
+    t_cache = time.perf_counter() - t0
+    # ---- decode steps of the same batch
+    nxt = torch.zeros(B, dtype=torch.int64, device=dev)
+    host_decode, ev = 0.0, []
+    for _ in range(decode_steps):
+        t0 = time.perf_counter()
+        batch.output_ids = nxt
+        batch.prepare_for_decode()
+        host_decode += time.perf_counter() - t0
+        ev.append(forward(batch, B))
+    torch.cuda.synchronize()
+    backend.check()
+    dec_us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)[len(ev) // 2]
+    flops = 4 * Hq * D * sum(e * p + e * (e + 1) // 2 for e, p in zip([len(r.fill_ids) - h for r, h in zip(reqs, hit)], hit))
+    return {"workload": f"{groups} groups x {per_group} requests, {prefix}-token shared prefix served from the radix tree, {suffix[0]}..{suffix[1]} new "
+                        f"tokens, then {decode_steps} decode steps; {layers} layers of the Llama-3-8B attention path",
+            "tree": "native (libmi355radix.so)" if native_tree else "python", "heads_per_gpu": [Hq, Hkv, D], "page_size": ps,
+            "prefix_hit_tokens": hit[0] if len(set(hit)) == 1 else hit, "new_tokens": T,
+            "host_match_prefix_ms_total": round(t_match * 1e3, 3), "host_prepare_for_prefill_ms": round(t_prep * 1e3, 3),
+            "host_cache_unfinished_ms_total": round(t_cache * 1e3, 3),
+            "prefill_us_per_layer": round(prefill_us / layers, 2), "prefill_tflops": round(flops / (prefill_us / layers) / 1e6, 1),
+            "host_prepare_for_decode_us_per_step": round(host_decode / decode_steps * 1e6, 1),
+            "decode_us_per_layer_median": round(dec_us / layers, 2),
+            "decode_attn_path_ms_per_step": round(dec_us / 1e3, 4)}

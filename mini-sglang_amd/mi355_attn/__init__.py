@@ -9,7 +9,9 @@ from .batch import Batch, Mode, Req, SamplingParams
 from .kvcache import KVCache
 from .page_manager import PageManager
 from .radix_cache import PagedRadixCache
+from .select import BACKEND_CHOICES, add_backend_argument, backend_class, select_backend
 from .tp import HeadShard, all_reduce_rows, shard_heads
 
 __all__ = ["Attention", "MI355AttnBackend", "Batch", "Mode", "Req", "SamplingParams", "KVCache", "PageManager",
-           "PagedRadixCache", "HeadShard", "shard_heads", "all_reduce_rows"]
+           "PagedRadixCache", "HeadShard", "shard_heads", "all_reduce_rows", "select_backend", "backend_class",
+           "add_backend_argument", "BACKEND_CHOICES"]

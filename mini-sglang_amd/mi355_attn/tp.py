@@ -199,6 +199,8 @@ class FusedRowParallel:
             outs = [torch.empty((T, self.N), dtype=xs[0].dtype, device=xs[0].device) for _ in xs]
         else:
             outs = out if self.local else (out,)
+        if T == 0:                         # nothing is launched, so this is not a call: the epoch (buffer half) must not move
+            return outs if self.local else outs[0]
         arr = self._entries(len(xs))
         for e, xi, wi, oi in zip(arr, xs, ws, outs):
             if not (xi.is_cuda and wi.is_cuda and oi.is_cuda):
@@ -217,6 +219,23 @@ class FusedRowParallel:
         return outs if self.local else outs[0]
 
     def check(self) -> None:
-        """Raise if a wait inside any earlier call gave up (a rank never arrived).  Synchronises: tests / diagnostics."""
+        """Raise if a wait inside any earlier call gave up (a rank never arrived; that call's rows are NaN and this
+        instance is out of step with its peers from then on).  Synchronises: call it where the caller syncs anyway."""
         if int(self.error.item()):
-            raise self._lib.MI355AttnError("FusedRowParallel: a peer's tile never arrived (bounded wait gave up)")
+            raise self._lib.MI355AttnError("FusedRowParallel: a peer's tile never arrived (bounded wait gave up); the instance "
+                                           "is unusable until every rank re-zeroes its buffers")
+
+    def poll_error(self):
+        """Non-blocking form for loops that never synchronise (a replayed graph): starts an asynchronous copy of the error
+        word and raises if an EARLIER poll's copy has arrived non-zero.  Call every N steps."""
+        pend = getattr(self, "_pend", None)
+        if pend is not None and pend[1].query():
+            if int(pend[0].item()):
+                raise self._lib.MI355AttnError("FusedRowParallel: a peer's tile never arrived (bounded wait gave up)")
+            pend = None
+        if pend is None:
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(self.error, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pend = (host, ev)

@@ -73,6 +73,9 @@ FLOW_CASES = [
     # BASELINE.json configs[0]: Llama-3.2-1B, page_size 1, batch 1, 128-token prompt (cut 4 like
     # bench_one_batch.py:147-188), 16 decode steps
     ("ps1_1b", 1, (32, 8, 64), [128], [4], 16),
+    # IEEE half (the reference takes the dtype from the checkpoint, utils/model_config.py:40-42; Llama-2-style checkpoints
+    # are fp16): Llama-2-7B at TP4 per rank, MHA.  The fixture also carries the reference's fp16 pools / outputs as hashes.
+    ("ps16_llama2_f16", 16, (8, 8, 128), [70, 33, 18], [64, 1, 17], 3, "f16"),
 ]
 
 
@@ -121,7 +124,12 @@ def run_flow(name, ps, heads, lens, cuts, steps, dtype):
         out[f"{tag}.free_head"] = np.array([int(x) for x in kv.free_pages[:4]], dtype=np.int64)
         assert [int(x) for x in kv.free_pages] == o_pool.free_pages
         assert torch.equal(kv.k_cache[0], ok_pool) and torch.equal(kv.v_cache[0], ov_pool), (name, tag, "pools")
-        if dtype == torch.bfloat16:
+        if dtype == torch.float16:
+            assert torch.equal(o_ref, o_ora), (name, tag, "fp16 attention: oracle != reference")
+            out[f"{tag}.f16_k_pool_hash"] = np.uint64(fnv64(bits16(kv.k_cache[0])))
+            out[f"{tag}.f16_v_pool_hash"] = np.uint64(fnv64(bits16(kv.v_cache[0])))
+            out[f"{tag}.f16_o_hash"] = np.uint64(fnv64(bits16(o_ref)))
+        elif dtype == torch.bfloat16:
             assert torch.equal(o_ref, o_ora), (name, tag, "bf16 attention: oracle != reference")
             out[f"{tag}.k_pool_hash"] = np.uint64(fnv64(bits16(kv.k_cache[0])))
             out[f"{tag}.v_pool_hash"] = np.uint64(fnv64(bits16(kv.v_cache[0])))
@@ -191,12 +199,18 @@ def run_flow(name, ps, heads, lens, cuts, steps, dtype):
 
 
 def gen_flows(only=None):
-    for name, ps, heads, lens, cuts, steps in FLOW_CASES:
+    for name, ps, heads, lens, cuts, steps, *flags in FLOW_CASES:
         if only and name not in only:
             continue
         a = run_flow(name, ps, heads, lens, cuts, steps, torch.bfloat16)
         b = run_flow(name, ps, heads, lens, cuts, steps, torch.float32)
         merged = dict(a)
+        if "f16" in flags:                                   # the same flow once more with IEEE-half pools and inputs
+            for k_, v_ in run_flow(name, ps, heads, lens, cuts, steps, torch.float16).items():
+                if ".f16_" in k_:
+                    merged[k_] = v_
+                elif k_ in a and isinstance(v_, np.ndarray) and not k_.endswith("_hash"):
+                    assert np.array_equal(a[k_], v_), (name, k_)
         for k_, v_ in b.items():
             if k_.endswith(".o_f32") or k_.endswith(".o_f32_rows"):
                 merged[k_] = v_

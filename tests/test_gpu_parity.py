@@ -88,6 +88,60 @@ def test_flow_through_backend(path, device_free_list):
                                    err_msg=ph.tag + " vs oracle bf16")
 
 
+def _f16_fixtures():
+    return [p for p in flow_fixtures() if "p1.f16_o_hash" in np.load(p).files]
+
+
+@pytest.mark.parametrize("path", _f16_fixtures(), ids=fixture_id)
+def test_flow_through_backend_in_ieee_half(path):
+    """An oracle-pinned flow in fp16 (the reference takes the dtype from the checkpoint, utils/model_config.py:40-42):
+    prefill -> extend over the cached prefix -> decode steps through Batch + MI355AttnBackend with IEEE-half pools and
+    inputs.  Pools bit-exact against the REFERENCE's fp16 pools (fixture hashes), metadata bit-exact, attention within
+    tolerance of the reference's fp32 anchor and of the oracle's fp16 output."""
+    m, ops = _mods()
+    fr = FlowReplay(path, torch.float16)
+    ps, Hq, Hkv, D = fr.ps, fr.Hq, fr.Hkv, fr.D
+    kv = m.KVCache(size=fr.S_pages * ps, page_size=ps, head_num=Hkv, head_dim=D, dtype=torch.float16, layer_num=1, device=DEV,
+                   device_free_list=True)
+    pm = m.PageManager(page_size=ps, max_req_num=fr.max_req, max_context_len=fr.ctx, device=DEV)
+    backend = m.MI355AttnBackend(SimpleNamespace(device=DEV, page_size=ps, kvcache=kv, page_manager=pm))
+    layer = m.Attention(layer_id=0, num_heads=Hq, num_kv_heads=Hkv, head_dim=D, scale=D ** -0.5)
+    reqs, batch = None, None
+    for ph in fr.phases():
+        if ph.tag == "p1":
+            reqs = [m.Req(i, fr.ids[i][: fr.cuts[i]]) for i in range(fr.n)]
+            for r in reqs:
+                r.fill_ids = list(r.origin_input_ids)
+            batch = m.Batch(reqs, page_manager=pm, kvcache=kv, device=DEV)
+            batch.prepare_for_prefill()
+        elif ph.tag == "p2":
+            for i, r in enumerate(reqs):
+                r.fill_ids = list(fr.ids[i])
+                r.prefix_ppns = pm.page_table[i, : fr.cuts[i] // ps].tolist()
+            batch = m.Batch(reqs, page_manager=pm, kvcache=kv, device=DEV)
+            batch.prepare_for_prefill()
+        else:
+            batch.output_ids = torch.tensor(ph.next_ids, dtype=torch.int64, device=DEV)
+            batch.prepare_for_decode()
+        for f in META_FIELDS:
+            assert np.array_equal(getattr(batch, f).cpu().numpy(), fr.golden(ph.tag, f)), (ph.tag, f)
+        qkv = ph.qkv.to(DEV)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        backend.init_forward_metadata(batch)
+        batch.attn_backend = backend
+        o = layer(q, k, v, batch)
+        torch.cuda.synchronize()
+        backend.check()
+        assert o.shape == (q.shape[0], Hq * D) and o.dtype == torch.float16
+        kp, vp = kv.get_kv_cache(0)
+        assert fnv64(bits16(kp)) == int(fr.golden(ph.tag, "f16_k_pool_hash")), (ph.tag, "K pool vs the reference's")
+        assert fnv64(bits16(vp)) == int(fr.golden(ph.tag, "f16_v_pool_hash")), (ph.tag, "V pool vs the reference's")
+        rows_, ref = fr.golden_o_f32(ph.tag)
+        np.testing.assert_allclose(o.float().cpu().numpy()[rows_], ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=ph.tag)
+        np.testing.assert_allclose(o.float().cpu().numpy(), ph.out.float().numpy(), rtol=BF16_RTOL, atol=BF16_ATOL,
+                                   err_msg=ph.tag + " vs oracle fp16")
+
+
 def test_device_page_ring_follows_the_host_fifo():
     """Random serving trace - prefills, decode steps over page boundaries, finished requests giving pages back in
     odd orders, wrap-around of the ring - with the device free list against the same trace on the host FIFO:
@@ -304,6 +358,7 @@ def test_decode_fused_store_equals_store_then_attention(Hq, Hkv, D, ps, lens):
     assert torch.equal(o1, o2)
     ref = _gpu_decode_reference(q.contiguous(), kp1, vp1, dt, rows.tolist(), lens, ps, Hq)
     assert torch.allclose(o2.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    assert plan.error() == 0
 
 
 def test_decode_planned_more_ranges_than_waves():
@@ -330,6 +385,8 @@ def test_decode_planned_more_ranges_than_waves():
     plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
     o = ops.decode_attn_planned(q, kp, vp, plan, Hq)
     assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens)) == 0          # the share kernel, 3-4 publishers per merger
+    assert plan.error() == 0
 
 
 def test_decode_attn_softmax_spike():
@@ -522,7 +579,9 @@ def test_decode_cfg2_full_size_properties():
     q = torch.randn((B, Hq * D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
     dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
     outs = [ops.decode_attn(q, kp, vp, dt, dr, dl, ps, Hq, hint).float() for hint in (max(lens), 2 * max(lens))]
-    outs.append(ops.decode_attn_planned(q, kp, vp, ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens)), Hq).float())
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    outs.append(ops.decode_attn_planned(q, kp, vp, plan, Hq).float())
+    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens)) == 0 and plan.error() == 0     # the share kernel, no give-up
     for o in outs[1:]:
         assert torch.allclose(o, outs[0], rtol=BF16_RTOL, atol=BF16_ATOL)
     # torch fp32 reference on the GPU, one sequence at a time (same gather as the reference backend)
@@ -539,7 +598,7 @@ def test_decode_cfg2_full_size_properties():
 
 def test_random_configurations_sweep():
     """tools/stress_parity.py for a few seconds: random head shapes, page sizes, batch compositions and prefix
-    splits through planned decode with fused store, chunked decode and prefill, against torch fp32 on the GPU."""
+    splits through planned decode with fused store, the self-contained decode call and prefill, against torch fp32 on the GPU."""
     import subprocess
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py")
     # bf16 / IEEE half on the product library (it picks the decode kernel from the batch shape), then the dev build with

@@ -58,66 +58,6 @@ def test_latency_mode_emits_the_result_record(tmp_path):
     assert res["batch_size"] == 2 and res["decode_throughput"] > 0 and res["prefill_latency"] > 0
 
 
-def _run_ranks(cmd, env, timeout):
-    """Run a launcher command in its own process group; on timeout the WHOLE group is killed (ranks left behind by a killed
-    launcher would go on sharing the GPU with the tests that follow) and None is returned."""
-    import signal
-    import subprocess
-    from types import SimpleNamespace
-    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        out, err = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        try:
-            os.killpg(p.pid, signal.SIGKILL)
-        except ProcessLookupError:
-            pass
-        p.communicate()
-        return None
-    return SimpleNamespace(returncode=p.returncode, stdout=out, stderr=err)
-
-
-def test_tp2_rehearsal_matches_tp1_first_tokens():
-    """The head-sharded path end to end (models/llama.py:76-87 sharding, layers/linear.py:228-232 all-reduces): two
-    ranks of bench_one_batch on this one GPU over gloo pass the three-phase correctness test, and the first token
-    each prompt generates is the single-GPU one (later tokens may part ways: bf16 sums in a different order)."""
-    import re
-    import subprocess
-    script = os.path.join(os.path.dirname(HERE), "mini-sglang_amd", "bench_one_batch.py")
-    args = ["--model", "tiny", "--correctness-test", "--batch-size", "3", "--input-len", "70", "--output-len", "6", "--cut-len", "32"]
-    env = dict(os.environ, M355_BENCH_REHEARSE="1")
-    one = subprocess.run([sys.executable, script] + args, capture_output=True, text=True, timeout=60)
-    two = _run_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                      "127.0.0.1", "--master-port", "29517", script] + args, env, 60)
-    if two is None:
-        pytest.skip("the two-rank gloo run did not finish on this box within 60 s")
-    assert one.returncode == 0 and "correctness: PASS" in one.stdout, one.stdout[-2000:] + one.stderr[-2000:]
-    assert two.returncode == 0 and "correctness: PASS" in two.stdout, two.stdout[-2000:] + two.stderr[-2000:]
-    first = lambda out: [int(x) for x in re.findall(r"Prompt \d+ =+ \[(\d+)", out)]
-    assert len(first(one.stdout)) == 3 and first(one.stdout) == first(two.stdout)
-
-
-def test_tp2_graphed_decode_with_the_fused_epilogue():
-    """Two ranks on this one GPU: the decode step captured as a HIP graph with the row-parallel layers' GEMM + all-reduce
-    as one-launch kernels inside it (m355_oproj_allreduce, epochs kept on the device) generates the tokens of the eager
-    two-rank loop, and passes the three-phase correctness test."""
-    import subprocess
-    script = os.path.join(os.path.dirname(HERE), "mini-sglang_amd", "bench_one_batch.py")
-    args = ["--model", "tiny", "--correctness-test", "--graph", "--fused-row-parallel", "--batch-size", "3", "--input-len", "70",
-            "--output-len", "8", "--cut-len", "32"]
-    env = dict(os.environ, M355_BENCH_REHEARSE="1")
-    two = _run_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                      "127.0.0.1", "--master-port", "29519", script] + args, env, 60)
-    if two is None:
-        pytest.skip("the two ranks' kernels did not run side by side on this one GPU (every bounded wait ran out)")
-    if "fused row-parallel waits gave up: True" in two.stdout:
-        # a property of sharing one GPU between two processes, not of the kernels: with a GPU per rank a wait only gives up
-        # when a peer is gone.  The tokens after a give-up mean nothing, so there is nothing to compare.
-        pytest.skip("a bounded wait gave up: the device did not overlap the two processes' kernels in this run")
-    assert two.returncode == 0 and "correctness: PASS" in two.stdout, two.stdout[-2000:] + two.stderr[-2000:]
-    assert "graphed decode tokens identical to the eager loop: True" in two.stdout, two.stdout[-2000:]
-
-
 @pytest.mark.parametrize("model,ps", [("tiny", 16), ("tiny128", 4)])
 def test_graphed_decode_equals_the_eager_loop(model, ps):
     """One decode step captured as a HIP graph (device free list, in-place metadata, fixed plan layout) and replayed

@@ -375,3 +375,52 @@ def test_group_sizes_run_in_the_next_built_one():
         _group_pad(72, 8)
     with pytest.raises(MI355AttnError):
         _group_pad(30, 8)
+
+
+# ------------------------------------------------------------------------------------------------
+# backend selection by name (the flag engine/model_runner.py:90-91 and utils/args.py lack)
+# ------------------------------------------------------------------------------------------------
+def test_select_backend_dispatch_and_refusal(monkeypatch):
+    import argparse
+    import sys
+    import types
+    from types import SimpleNamespace
+    m = _m()
+    runner = SimpleNamespace(device="cuda", page_size=16)
+    # this package's backend, under every spelling
+    for name in ("mi355", "MI355", " mi355x ", "hip"):
+        b = m.select_backend(name, runner)
+        assert type(b) is m.MI355AttnBackend and b.page_size == 16 and b.device == "cuda"
+    # unknown names are refused with the choices listed - no default, no fallback
+    with pytest.raises(ValueError, match="mi355, torch_native, fa3"):
+        m.select_backend("flashinfer", runner)
+    # the reference's backends are imported lazily, by name, from whatever `minisglang` is on the path
+    assert not any(k.startswith("minisglang") for k in sys.modules), "importing mi355_attn must not import the reference"
+    made = []
+
+    class FakeNative:
+        def __init__(self, model_runner):
+            made.append(model_runner)
+
+    pkgs = ["minisglang", "minisglang.layers", "minisglang.layers.attention_backends"]
+    for p in pkgs:
+        mod = types.ModuleType(p)
+        mod.__path__ = []                                       # a package with nothing importable inside
+        monkeypatch.setitem(sys.modules, p, mod)
+    leaf = types.ModuleType(pkgs[-1] + ".torch_native_backend")
+    leaf.TorchNativeAttnBackend = FakeNative
+    monkeypatch.setitem(sys.modules, leaf.__name__, leaf)
+    for name in ("torch_native", "torch-native", "sdpa"):
+        assert type(m.select_backend(name, runner)) is FakeNative
+    assert made == [runner] * 3
+    # ... and one whose module is missing (FA3 needs sgl_kernel, flash_attention_backend.py:5) says so, loudly
+    with pytest.raises(ImportError, match="fa3"):
+        m.select_backend("fa3", runner)
+    # the argparse piece: --attention-backend next to --page-size
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--page-size", type=int, default=1)
+    m.add_backend_argument(ap)
+    assert ap.parse_args([]).attention_backend == "mi355"
+    assert ap.parse_args(["--attention-backend", "Torch-Native"]).attention_backend == "torch_native"
+    with pytest.raises(SystemExit):
+        ap.parse_args(["--attention-backend", "nope"])

@@ -71,6 +71,29 @@ def test_flow_attention_bf16_and_f64_anchor(path):
         np.testing.assert_allclose(f64.reshape(T, -1).numpy()[rows], ref, rtol=1e-4, atol=1e-5, err_msg=ph.tag)
 
 
+def _f16_fixtures():
+    return [p for p in flow_fixtures() if "p1.f16_o_hash" in np.load(p).files]
+
+
+@pytest.mark.parametrize("path", _f16_fixtures(), ids=fixture_id)
+def test_flow_in_ieee_half_matches_reference(path):
+    """The flows generated a third time with IEEE-half pools and inputs (Llama-2-style fp16 checkpoints): the oracle
+    replays them to the reference's fp16 pool contents bit for bit, and to its fp16 SDPA outputs (bitwise on the generating
+    host, otherwise within the half-precision tolerance of the fp32 anchor)."""
+    fr = FlowReplay(path, torch.float16)
+    for ph in fr.phases():
+        assert fnv64(bits16(ph.k_pool)) == int(fr.golden(ph.tag, "f16_k_pool_hash")), (ph.tag, "k pool")
+        assert fnv64(bits16(ph.v_pool)) == int(fr.golden(ph.tag, "f16_v_pool_hash")), (ph.tag, "v pool")
+        if fnv64(bits16(ph.out)) != int(fr.golden(ph.tag, "f16_o_hash")):
+            warnings.warn(f"{fixture_id(path)}:{ph.tag}: fp16 SDPA differs bitwise from the generating host")
+        rows, ref = fr.golden_o_f32(ph.tag)
+        np.testing.assert_allclose(ph.out.float().numpy()[rows], ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=ph.tag)
+
+
+def test_f16_fixture_present():
+    assert len(_f16_fixtures()) >= 1
+
+
 def test_out_cache_loc_dtype_promotion():
     table = np.arange(12, dtype=np.int32).reshape(3, 4)
     loc = M.out_cache_loc_ref(table, np.array([2, 0]), np.array([5, 3]), 2)

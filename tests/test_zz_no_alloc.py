@@ -1,8 +1,8 @@
 """The allocation-free entry point m355_decode_store_attn_planned_static (include/mi355attn.h) against the workspace
 form m355_decode_store_attn_planned, through the C ABI: same kernels, so pools AND outputs must be bit-identical
 (the bar for byte work; the workspace form itself is held to the bf16 tolerance against the oracle elsewhere).
-Two calls in a row on the same GPU share the library's scratch array: the second, smaller, call must not see
-anything of the first.  Collected last (test_zz_*): the round's end runs pytest -x."""
+Calls in a row on the same GPU share the library's scratch array (used by the per-wave-range kernel's partials; the
+single-launch share kernel needs none): a smaller call after a larger one must not see anything of it.  Collected last (test_zz_*): the round's end runs pytest -x."""
 import ctypes
 
 import numpy as np
@@ -62,6 +62,7 @@ def _run_both(ops, lib, B, Hq, Hkv, D, ps, lens, seed):
     assert torch.equal(kp1, kp2) and torch.equal(vp1, vp2)
     assert torch.equal(o1, o2)
     assert torch.isfinite(o2.float()).all()
+    assert plan.error() == 0
     return need
 
 
@@ -70,15 +71,21 @@ def test_static_scratch_entry_equals_workspace_entry():
     from mi355_attn import _lib, ops
     lib = _lib.load()
     rng = np.random.default_rng(0)
-    # 1. cfg2-sized: B = 64 ragged, 1B head shape: the single-launch kernel, whose scratch holds the partials of the
-    #    requests a share boundary cuts (handed over between workgroups)
+    # 1. cfg2-sized: B = 64 ragged, 1B head shape: served by the single-launch share kernel, which needs NO scratch (the
+    #    partials of requests a share boundary cuts travel inside the plan buffer): need1 == 0, the array is not touched
     lens = [int(x) for x in rng.integers(64, 2049, size=64)]
     need1 = _run_both(ops, lib, 64, 32, 8, 64, 16, lens, seed=1)
-    # 2. right after it, a SMALLER batch with another head shape (few requests per CU: per-wave ranges + merge
-    #    launch, whose fp32 partials reuse the front of the same scratch array)
+    # 2. right after it, a SMALLER batch with another head shape (few requests per CU: per-wave ranges + merge, whose
+    #    fp32 partials DO live in the scratch array): need2 > 0 - this is the case that exercises the array
     lens2 = [int(x) for x in rng.integers(1, 700, size=5)]
     need2 = _run_both(ops, lib, 5, 8, 1, 128, 16, lens2, seed=2)
+    assert need1 == 0 and need2 > 0, "case 2 must be the scratch-using kernel"
     assert sum(lens2) < sum(lens) and max(need1, need2) <= ops.STATIC_SCRATCH_BYTES
+    # 2b. a larger scratch user first, then the smaller one again: the second call must see nothing of the first
+    lens3 = [int(x) for x in rng.integers(300, 1500, size=12)]
+    need3 = _run_both(ops, lib, 12, 8, 1, 128, 16, lens3, seed=4)
+    assert need3 > need2
+    _run_both(ops, lib, 5, 8, 1, 128, 16, lens2, seed=2)
     # 3. the wrapper form, page_size 1
     table, kp, vp, qkv = _case(3, 16, 4, 128, 1, [300, 17, 1], 3)
     dqkv = qkv.to(DEV)

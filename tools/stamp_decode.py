@@ -16,7 +16,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "mini-sglang_amd"))
 os.environ.setdefault("M355_DECODE_VARIANT", "17")
-STREAM = os.environ.get("STAMP_STREAM") == "1"
+STREAM = True        # (the round-1 chunked kernel this tool also stamped is gone: the per-wave-range kernel only)
 if STREAM:
     os.environ["M355_STREAM_VARIANT"] = "0"
     os.environ["M355_STREAM_STAMP"] = "1"
@@ -46,7 +46,7 @@ max_splits = -(-max_len // chunk)
 nblocks = 256 * 8 if STREAM else B * Hkv * max_splits
 stamps = torch.zeros((nblocks, 8), dtype=torch.int64, device=dev)
 lib = _lib.load()
-setter = lib.m355dbg_set_stream_stamp_buffer if STREAM else lib.m355dbg_set_stamp_buffer
+setter = lib.m355dbg_set_stream_stamp_buffer
 setter.argtypes = [ctypes.c_void_p]
 assert setter(stamps.data_ptr()) == 0
 plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens)) if STREAM else None
