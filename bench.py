@@ -234,7 +234,9 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
     out["prefill_cfg3" if tp == 1 else "prefill_cfg3_per_rank"] = guarded(prefill_cfg3, dev, tp)
     if tp == 1:
         note(rank, "cfg3 end to end through the radix tree")
-        out["cfg3_flow"] = {"native_tree": guarded(W.cfg3_flow, dev, True), "python_tree": guarded(W.cfg3_flow, dev, False)}
+        guarded(W.cfg3_flow, dev, True)                      # untimed pass: first-use costs of this batch shape (module loads, pinned buffers)
+        out["cfg3_flow"] = {"native_tree": guarded(W.cfg3_flow, dev, True), "python_tree": guarded(W.cfg3_flow, dev, False),
+                            "protocol": "one untimed pass of the whole flow first; host times are wall clock, GPU times HIP events"}
     note(rank, "fused o_proj probe (child processes)" if tp > 1 else "bench_one_batch")
     fused_ok = tp > 1 and fused_probe(dev, tp)
     if tp > 1:

@@ -236,7 +236,8 @@ def cfg3_flow(dev: str, native_tree: bool = True, Hq: int = 32, Hkv: int = 8, D:
         b0.prepare_for_prefill()
         forward(b0, len(r.fill_ids))
         r.output_ids.append(1)
-        tree.cache_finished_req(r)
+        tree.cache_unfinished_req(r)                         # the life cycle of scheduler.py:415-436: cached after its prefill ...
+        tree.cache_finished_req(r)                           # ... and released when it finishes (also: first-use costs land here)
     torch.cuda.synchronize()
     # ---- the 16 requests, one batch
     reqs = [m.Req(i, list(p), m.SamplingParams(max_new_tokens=decode_steps + 1)) for i, p in enumerate(prompts)]
