@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling passes)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (see measure_traffic())")
     ap.add_argument("--fused-probe", action="store_true", help="internal: child of an N>1 run, see fused_probe()")
     ap.add_argument("--one-batch-graph-child", action="store_true", help="internal: child of an N>1 run, see one_batch_graph_tp()")
     ap.add_argument("--heads", type=str, default="", help="experiment: Hq,Hkv,D per GPU instead of the 1B shape")
@@ -95,6 +96,12 @@ def main():
     rehearse = os.environ.get("M355_BENCH_REHEARSE") == "1"            # dev: all ranks on cuda:0 over gloo (one-GPU box)
     if rehearse:
         local_rank = 0
+    experiment = bool(args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1)
+    measured = None
+    if world == 1 and not experiment and not args.no_pmc:
+        note(0, "HBM traffic: two rocprofv3 --pmc child passes of the headline leg")
+        measured = measure_traffic()                   # child processes, BEFORE this process touches the GPU
+        note(0, "HBM traffic measured" if measured else "HBM traffic not measured here: falling back to the committed summary")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
@@ -110,7 +117,6 @@ def main():
     tp = world
     shard = shard_heads(MODEL["Hq"], MODEL["Hkv"], MODEL["D"], tp, rank)    # refuses tp > num_kv_heads
     Hq, Hkv, D, L = shard.num_heads, shard.num_kv_heads, MODEL["D"], MODEL["layers"]
-    experiment = bool(args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1)
     if args.heads:
         Hq, Hkv, D = (int(x) for x in args.heads.split(","))
     ps = PAGE_SIZE
@@ -156,7 +162,7 @@ def main():
     us_per_launch, bytes_launch = W.time_decode_launches(case, reps=20)
     achieved = bytes_launch / us_per_launch / 1e3
     kernel = W.decode_kernel_name(case)
-    traffic, traffic_source = (None, None) if (tp > 1 or experiment) else pmc_traffic(kernel)
+    traffic, traffic_source = (None, None) if (tp > 1 or experiment) else pmc_traffic(kernel, measured)
 
     cpu = None
     if rank == 0 and tp == 1 and not args.no_cpu_baseline:
@@ -530,12 +536,67 @@ def collective_legs(dev, tp, rank, rehearse, fence, fused_ok=False):
                                      "T4863": {f"chunks{c}": o_proj(4863, c, 10) for c in (1, 2, 4, 8)}}}}
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per attention launch from the newest committed PMC summary of this same command
-    (profiles/rNN_pmc_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE and WRITE_SIZE
-    passes, corrected per MI355X_MICROARCH.md).  NOT measured in this run: the second value names the file."""
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+PMC_CHILD = ["--no-cpu-baseline", "--no-extras", "--no-pmc", "--steps", "4", "--warmup", "2"]
+
+
+def measure_traffic():
+    """HBM bytes per launch of this command's kernels, measured by THIS run: the headline leg is run twice more as a child
+    under `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` (a pass of its own each, nothing but --pmc, as
+    MI355X_MICROARCH.md's HBM section prescribes), before this process touches the GPU.  Both counters are in KiB; on gfx950
+    FETCH_SIZE tallies 128-byte requests at 64 bytes, so reads are doubled.  Returns {kernel name: bytes per launch} plus a
+    "source" entry, or None (no rocprofv3, already running under a profiler, a pass failed): pmc_traffic() then falls back to
+    the newest committed summary and says so."""
+    import shutil
+    import sqlite3
+    import tempfile
+    if shutil.which("rocprofv3") is None or shutil.which("timeout") is None:
+        return None
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None                                    # this run is itself being profiled: no nesting
+    acc = {}
+    with tempfile.TemporaryDirectory(prefix="m355pmc") as tmp:
+        env = dict(os.environ, TMPDIR=tmp)
+        for leg, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            out = os.path.join(tmp, leg)
+            cmd = ["timeout", "-s", "KILL", "150", "rocprofv3", "--pmc", counter, "-d", out, "-o", leg, "--",
+                   sys.executable, os.path.abspath(__file__)] + PMC_CHILD
+            try:
+                r = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=170)
+            except Exception:                           # noqa: BLE001
+                return None
+            dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            try:
+                db = sqlite3.connect(dbs[0])
+                rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+                                  "and kernel_name like '%m355::%' group by kernel_name", (counter,)).fetchall()
+                db.close()
+            except Exception:                           # noqa: BLE001
+                return None
+            if not rows:
+                return None
+            for name, _calls, kib in rows:
+                acc[name] = acc.get(name, 0) + int(kib * 1024 * (2 if counter == "FETCH_SIZE" else 1))
+    acc["source"] = ("measured by this run: child passes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one pass each) of "
+                     "`bench.py " + " ".join(PMC_CHILD) + "`; KiB*1024, reads doubled (gfx950)")
+    return acc
+
+
+def pmc_traffic(kernel: str, measured=None):
+    """HBM bytes per attention launch: from this run's own PMC passes (measure_traffic) when they ran, else from the newest
+    committed summary of the same command (profiles/rNN_pmc_traffic.json, tools/summarize_profile.py).  The second value says
+    which."""
     want = [w.split("::")[-1].strip(" ()+") for w in kernel.split("(+") if w.strip()]
+    if measured:
+        tot, ok = 0, True
+        for w in want:
+            hit = [v for k, v in measured.items() if k != "source" and w in k]
+            ok = ok and bool(hit)
+            tot += hit[0] if hit else 0
+        if ok:
+            return tot, measured["source"]
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
     for path in reversed(files):
         with open(path) as f:
             kernels = json.load(f)["kernels"]

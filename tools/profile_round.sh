@@ -11,7 +11,7 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --no-cpu-baseline --no-extras"      # the headline workload alone (the extras run other kernels / shapes)
+BENCH="python3 bench.py --no-cpu-baseline --no-extras --no-pmc"      # the headline workload alone (the extras run other kernels / shapes)
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 echo "stats pass done"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $BENCH --steps 4 --warmup 2 > $OUT/fetch.log 2>&1
