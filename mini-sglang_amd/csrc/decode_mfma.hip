@@ -37,6 +37,116 @@ __host__ __device__ inline int mfma_lds_bytes(int D, int G, int R, int slots_cap
     return R * 64 * D * 2 + kQP * G * 2 * D + slots_cap * 4 + 64 * 4;
 }
 
+// ---- In-kernel merge (DEV build only, M355_MERGE_IN_KERNEL=1): the pieces of a cut request count themselves in and the
+// last one to arrive merges, instead of the stream_merge_kernel launch.  Built and measured in round 3 and SLOWER on every
+// small-launch shape it was meant for ((8,1,128) B=64: 22.2 against 17.7 us; 32 768 tokens x B=1: 20.2 against 14.3;
+// profiles/r03_merge_ab.txt): write-through store -> acknowledged -> agent-scope count -> fetch past the own L2 are three
+// dependent trips to memory (~2 us each while the chip streams), more than the second launch costs.  Kept as an A/B.
+#ifdef M355_DEV
+constexpr bool kMergeBuilt = true;
+#else
+constexpr bool kMergeBuilt = false;
+#endif
+// partials in the workspace then travel at AGENT scope (sc1: written through by the store, fetched past the reader's own
+// L2 by the load): the pieces of one request are streamed on different XCDs, each with an L2 of its own, and the wave that
+// merges them runs in the same launch.  Raw buffer accesses carry the policy bit and stay inside hipcc's own wait counting.
+constexpr int kAuxAgent = 16;                   // cache policy operand of the buffer builtins on gfx950: sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <int VEC>
+__device__ __forceinline__ void ld_agent_vec(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float (&o)[VEC]) {
+    if constexpr (VEC == 1) {
+        o[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxAgent));
+    } else if constexpr (VEC == 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxAgent);
+        const uint32_t t0 = t[0], t1 = t[1];              // (hipcc 7.2: __builtin_bit_cast of a vector ELEMENT reads element 0)
+        o[0] = __builtin_bit_cast(float, t0); o[1] = __builtin_bit_cast(float, t1);
+    } else {
+#pragma unroll
+        for (int x = 0; x < VEC / 4; ++x) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * x, soff, kAuxAgent);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) { const uint32_t ty = t[y]; o[4 * x + y] = __builtin_bit_cast(float, ty); }
+        }
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void st_agent_vec(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float (&o)[VEC]) {
+    if constexpr (VEC == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[0]), r, voff, soff, kAuxAgent);
+    } else if constexpr (VEC == 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(uint32_t, o[0]), __builtin_bit_cast(uint32_t, o[1])}, r, voff, soff, kAuxAgent);
+    } else {
+#pragma unroll
+        for (int x = 0; x < VEC / 4; ++x)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(uint32_t, o[4 * x]), __builtin_bit_cast(uint32_t, o[4 * x + 1]),
+                                                         __builtin_bit_cast(uint32_t, o[4 * x + 2]), __builtin_bit_cast(uint32_t, o[4 * x + 3])},
+                                                   r, voff + 16 * x, soff, kAuxAgent);
+    }
+}
+
+// One wave combines `count` partials (first, first + stride, ...) of kv head h: a lane owns VEC consecutive values of
+// O[G][D] and the (m, l) of their q head.  PB partials' loads are in flight together (one memory latency per batch).
+template <int D, int G>
+__device__ __forceinline__ void merge_partials(const StreamParams& p, int h, int lane, int first, int count, int stride,
+                                               float& gm, float& den, float (&acc)[G * D / 64]) {
+    constexpr int VEC = G * D / 64;
+    constexpr int PB = VEC >= 16 ? 4 : 8;
+    const int e0 = lane * VEC, g = e0 / D;
+    const int64_t hq0 = (int64_t)first * p.Hq + h * G;
+    const __amdgpu_buffer_rsrc_t ro = ws_rsrc(p.ws_o + hq0 * D);
+    const __amdgpu_buffer_rsrc_t rml = ws_rsrc(p.ws_ml + hq0 * 2);
+    const uint32_t step_o = (uint32_t)stride * p.Hq * D * 4, step_ml = (uint32_t)stride * p.Hq * 8;
+    gm = kNegBig; den = 0.f;
+#pragma unroll
+    for (int x = 0; x < VEC; ++x) acc[x] = 0.f;
+    for (int j0 = 0; j0 < count; j0 += PB) {
+        float ml[PB][2], oo[PB][VEC];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const uint32_t jj = (uint32_t)__builtin_amdgcn_readfirstlane(j0 + j < count ? j0 + j : count - 1);
+            ld_agent_vec<2>(rml, g * 8, jj * step_ml, ml[j]);
+            ld_agent_vec<VEC>(ro, e0 * 4, jj * step_o, oo[j]);
+        }
+        float bm = gm;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) bm = fmaxf(bm, j0 + j < count ? ml[j][0] : kNegBig);
+        const float resc = exp2_fast(gm - bm);
+        den *= resc;
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) acc[x] *= resc;
+        gm = bm;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const float wgt = j0 + j < count ? exp2_fast(ml[j][0] - gm) : 0.f;
+            den = fmaf(wgt, ml[j][1], den);
+#pragma unroll
+            for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, oo[j][x], acc[x]);
+        }
+    }
+}
+
+template <int VEC, bool F16>
+__device__ __forceinline__ void store_out_vec(uint16_t* op, const float (&acc)[VEC], float inv) {
+    if constexpr (VEC == 1) {
+        *op = (uint16_t)(pack16<F16>(acc[0] * inv, 0.f) & 0xffffu);
+    } else {
+        uint32_t wds[VEC / 2];
+#pragma unroll
+        for (int x = 0; x < VEC / 2; ++x) wds[x] = pack16<F16>(acc[2 * x] * inv, acc[2 * x + 1] * inv);
+        if constexpr (VEC == 2) *reinterpret_cast<uint32_t*>(op) = wds[0];
+        else if constexpr (VEC == 4) *reinterpret_cast<uint2*>(op) = make_uint2(wds[0], wds[1]);
+        else {
+#pragma unroll
+            for (int x = 0; x < VEC / 8; ++x)
+                *reinterpret_cast<u32x4*>(op + 8 * x) = u32x4{wds[4 * x], wds[4 * x + 1], wds[4 * x + 2], wds[4 * x + 3]};
+        }
+    }
+}
+
 template <int D, int G, int R, bool STAMP, bool F16 = false>
 __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, const int slots_cap) {
     using M = MG<D>;
@@ -47,6 +157,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
     int32_t* const slots = reinterpret_cast<int32_t*>(qsp + kQP * G * M::ROWB);
     int32_t* const rec = slots + slots_cap;
     int32_t* const pc = rec + 4;                         // piece k: pc[4k .. 4k+3] = {request, start, length, partial index}
+    int32_t* const cutp = rec + kRecCut;                 // piece k: {pieces its request is cut into (0: whole), its ordinal}
 
     sstamp<STAMP>(p, 0);
     const int lane = threadIdx.x;
@@ -83,6 +194,9 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
 
     const bool fused = p.k_new != nullptr;
     uint32_t endmask = 0;                                // bit k: piece k of the range ends its request
+    // partial pieces of the current range that still have to count themselves in (a range's first and last piece only)
+    int nd = 0, da_b = 0, da_pidx = 0, da_tot = 0, da_k = 0, dz_b = 0, dz_pidx = 0, dz_tot = 0, dz_k = 0;
+    const __amdgpu_buffer_rsrc_t ws_o_r = ws_rsrc(p.ws_o), ws_ml_r = ws_rsrc(p.ws_ml);
 
     auto run_pass = [&](const int p0, const int np) {
         int lk = 0, lit = 0, ck = 0, cit = 0, issued = 0, consumed = 0;
@@ -153,7 +267,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
         // A finished piece's results wait in registers until the NEXT stage has been waited for: stored at once they
         // would sit in front of that stage in the vmcnt queue and the counted wait would include their write acknowledge.
         bool pend = false;
-        int pend_bq = 0, pend_pidx = 0;
+        int pend_bq = 0, pend_pidx = 0, pend_tot = 0, pend_k = 0;
         float pend_m = 0.f, pend_l = 0.f;
         f32x4 pend_O[M::DT];
         auto flush_piece = [&]() {
@@ -170,6 +284,14 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                         uint32_t w0 = pack16<F16>(O[dt][0] * inv, O[dt][1] * inv), w1 = pack16<F16>(O[dt][2] * inv, O[dt][3] * inv);
                         *reinterpret_cast<uint2*>(op + 16 * dt) = make_uint2(w0, w1);
                     }
+                } else if (kMergeBuilt && p.merge_in_kernel) {
+                    const uint32_t idx = (uint32_t)pidx * p.Hq + h * G + n;
+#pragma unroll
+                    for (int dt = 0; dt < M::DT; ++dt) {
+                        const float o4[4] = {O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
+                        st_agent_vec<4>(ws_o_r, (idx * D + 4 * kg + 16 * dt) * 4, 0, o4);
+                    }
+                    if (kg == 0) { const float ml2[2] = {m_run, l}; st_agent_vec<2>(ws_ml_r, idx * 8, 0, ml2); }
                 } else {
                     const int64_t idx = (int64_t)pidx * p.Hq + h * G + n;
                     float* wo = p.ws_o + idx * D + 4 * kg;
@@ -177,6 +299,11 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                     for (int dt = 0; dt < M::DT; ++dt) *reinterpret_cast<f32x4*>(wo + 16 * dt) = O[dt];
                     if (kg == 0) { p.ws_ml[idx * 2] = m_run; p.ws_ml[idx * 2 + 1] = l; }
                 }
+            }
+            if (kMergeBuilt && pidx >= 0 && p.merge_in_kernel) {        // (wave-uniform) the piece counts itself in when the range is done
+                if (nd == 0) { da_b = bq; da_pidx = pidx; da_tot = pend_tot; da_k = pend_k; }
+                else { dz_b = bq; dz_pidx = pidx; dz_tot = pend_tot; dz_k = pend_k; }
+                ++nd;
             }
         };
         auto end_piece = [&]() {
@@ -187,8 +314,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
             lane_pair<32>(l, a, b);
             pend_l = a + b;
             pend_m = m_run;
-            pend_bq = pc[(p0 + ck) * 4 + 0];
-            pend_pidx = pc[(p0 + ck) * 4 + 3];
+            pend_bq = __builtin_amdgcn_readfirstlane(pc[(p0 + ck) * 4 + 0]);
+            pend_pidx = __builtin_amdgcn_readfirstlane(pc[(p0 + ck) * 4 + 3]);
+            pend_tot = __builtin_amdgcn_readfirstlane(cutp[(p0 + ck) * 2]);
+            pend_k = __builtin_amdgcn_readfirstlane(cutp[(p0 + ck) * 2 + 1]);
 #pragma unroll
             for (int dt = 0; dt < M::DT; ++dt) pend_O[dt] = O[dt];
             pend = true;
@@ -349,7 +478,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
                     pc[k * 4 + 0] = bb;
                     pc[k * 4 + 1] = lo - g0;
                     pc[k * 4 + 2] = hi - lo;
-                    pc[k * 4 + 3] = (lo == cs && hi == ce) ? -1 : pbase[bb] + (r - cs / Rt);
+                    const bool whole = lo == cs && hi == ce;
+                    pc[k * 4 + 3] = whole ? -1 : pbase[bb] + (r - cs / Rt);
+                    cutp[k * 2] = whole ? 0 : (ce - 1) / Rt - cs / Rt + 1;
+                    cutp[k * 2 + 1] = whole ? 0 : r - cs / Rt;
                 }
                 const unsigned long long ends = __ballot(have && hi == ce && plan[p.off_full + bb] != 0);
                 endmask = 0;
@@ -362,6 +494,45 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
             }
             for (int p0 = 0; p0 < np; p0 += kQP) run_pass(p0, min(kQP, np - p0));
         } while (scanning && done < nt);
+        // ---- the range's partial pieces count themselves in; whoever completes a count merges
+        if (kMergeBuilt && nd > 0) {
+            wait_vmcnt<0>();                             // this wave's partials have been written through
+            constexpr int VEC = G * D / 64;
+            const int e0 = lane * VEC, gq = e0 / D, d0 = e0 - gq * D;
+            int32_t* const arrivals = const_cast<int32_t*>(plan) + p.off_arrivals;
+            if (nd > 2 && lane == 0)                     // (cannot happen: only a range's first and last piece are parts of longer requests)
+                __hip_atomic_store(const_cast<int32_t*>(plan) + M355_PLAN_ERROR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < (nd < 2 ? nd : 2); ++i) {
+                const int bq = i ? dz_b : da_b, pidx = i ? dz_pidx : da_pidx, tot = i ? dz_tot : da_tot, k = i ? dz_k : da_k;
+                const int gs = merge_group(tot);
+                const int gi = k / gs, ng = (tot + gs - 1) / gs;
+                const int n_g = tot - gi * gs < gs ? tot - gi * gs : gs;
+                const int pf = pidx - k + gi * gs;       // the group's first partial
+                int32_t* const c1 = arrivals + (int64_t)pf * p.Hkv + h;
+                int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old != n_g - 1) continue;
+                if (lane == 0) __hip_atomic_store(c1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                float gm, den, acc[VEC];
+                merge_partials<D, G>(p, h, lane, pf, n_g, 1, gm, den, acc);
+                if (ng > 1) {                            // two levels: leave ONE partial in the place of the group's first piece
+                    const uint32_t idx = (uint32_t)pf * p.Hq + h * G + gq;
+                    st_agent_vec<VEC>(ws_o_r, (idx * D + d0) * 4, 0, acc);
+                    if (d0 == 0) { const float ml2[2] = {gm, den}; st_agent_vec<2>(ws_ml_r, idx * 8, 0, ml2); }
+                    wait_vmcnt<0>();
+                    int32_t* const c2 = arrivals + (int64_t)(pidx - k + 1) * p.Hkv + h;   // (never a group's first partial: groups are >= 16 apart)
+                    old = 0;
+                    if (lane == 0) old = __hip_atomic_fetch_add(c2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    if (old != ng - 1) continue;
+                    if (lane == 0) __hip_atomic_store(c2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    merge_partials<D, G>(p, h, lane, pidx - k, ng, gs, gm, den, acc);
+                }
+                store_out_vec<VEC, F16>(p.out + (int64_t)bq * p.o_stride + (int64_t)(h * G + gq) * D + d0, acc, 1.f / den);
+            }
+            nd = 0;
+        }
     }
     if constexpr (STAMP) { sstamp<STAMP>(p, 4); wait_vmcnt<0>(); sstamp<STAMP>(p, 5); }
 }

@@ -57,7 +57,7 @@ __device__ __forceinline__ int32_t pieces_of(int32_t a, int32_t e, int32_t R) { 
 
 constexpr int kCumLds = 4096;                       // requests whose cumulative lengths the plan kernels stage in LDS
 
-__global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nwh,
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restrict__ seq_lens, int32_t B, int32_t nwh, int32_t Hkv,
                                                          int32_t r_min, int64_t cap, int64_t wmax, int32_t* __restrict__ plan,
                                                          PlanLayout L) {
     __shared__ int32_t wsum[16];
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
         run += pieces_of(cu[b], cu[b + 1], R);
     }
     if (tid == 1023) { pbase[B] = run; if (staged) pb_s[B] = run; }
+    for (int64_t k = tid; k < ((int64_t)L.max_ranges + B) * Hkv; k += 1024) plan[L.arrivals + k] = 0;
     __syncthreads();
     const int32_t* pb = staged ? pb_s : pbase;
     // range records
@@ -140,7 +141,10 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
             rec[4 + np * 4 + 0] = b;
             rec[4 + np * 4 + 1] = lo2 - g0;
             rec[4 + np * 4 + 2] = hi2 - lo2;
-            rec[4 + np * 4 + 3] = (lo2 == cs && hi2 == ce) ? -1 : pb[b] + (r - cs / R);
+            const bool whole = lo2 == cs && hi2 == ce;
+            rec[4 + np * 4 + 3] = whole ? -1 : pb[b] + (r - cs / R);
+            rec[kRecCut + 2 * np] = whole ? 0 : pieces_of(cs, ce, R);
+            rec[kRecCut + 2 * np + 1] = whole ? 0 : r - cs / R;
             if (hi2 == ce && (int64_t)(ce - cs) == seq_lens[b]) endmask |= 1 << np;   // (a cut request has no newest slot)
             ++np;
         }
@@ -596,7 +600,7 @@ extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int
     if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
     if (share_mode(B, Hkv, D, G, token_capacity))
         return share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G).ints * (int64_t)sizeof(int32_t);
-    return plan_layout(B, stream_nwh(Hkv, D, G, token_capacity), token_capacity).ints * (int64_t)sizeof(int32_t);
+    return plan_layout(B, stream_nwh(Hkv, D, G, token_capacity), Hkv, token_capacity).ints * (int64_t)sizeof(int32_t);
 }
 
 extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_table_ids, const int32_t* page_table,
@@ -615,10 +619,10 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
                                  (int32_t*)plan, (hipStream_t)stream);
     }
     const int nwh = stream_nwh(Hkv, D, G, token_capacity);
-    const PlanLayout L = plan_layout(B, nwh, token_capacity);
+    const PlanLayout L = plan_layout(B, nwh, Hkv, token_capacity);
     if (plan_bytes < L.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, nwh, stream_rmin(D, G), token_capacity,
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, st, seq_lens, B, nwh, Hkv, stream_rmin(D, G), token_capacity,
                        (int64_t)pt_cols * page_size, (int32_t*)plan, L);
     int64_t blocks = (token_capacity + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -631,7 +635,7 @@ extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, in
                                                        int64_t token_capacity) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return 0;
     if (share_mode(B, Hkv, D, Hq / Hkv, token_capacity)) return 0;      // single launch: partials never leave LDS (hand-offs ride in the plan)
-    const PlanLayout L = plan_layout(B, stream_nwh(Hkv, D, Hq / Hkv, token_capacity), token_capacity);
+    const PlanLayout L = plan_layout(B, stream_nwh(Hkv, D, Hq / Hkv, token_capacity), Hkv, token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;      // every range boundary and request adds at most one
     return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
 }
@@ -699,7 +703,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
         return rc != M355_OK ? rc : check_launch();
     }
     const int nwh = stream_nwh(Hkv, D, G, token_capacity);
-    const PlanLayout L = plan_layout(B, nwh, token_capacity);
+    const PlanLayout L = plan_layout(B, nwh, Hkv, token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;
     const int64_t need = n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return M355_ERR_WORKSPACE;
@@ -709,7 +713,11 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     p.k_new = (const uint16_t*)k_new; p.v_new = (const uint16_t*)v_new; p.kn_stride = k_row_stride; p.vn_stride = v_row_stride;
     p.ws_o = (float*)workspace; p.ws_ml = p.ws_o + n_partials * Hq * D;
     p.q_stride = q_row_stride; p.o_stride = o_row_stride; p.row_elems = pool_row_stride;
-    p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_full = L.full; p.off_rec = L.rec; p.off_slots = L.slots;
+    p.off_cum = L.cum; p.off_pbase = L.pbase; p.off_full = L.full; p.off_arrivals = L.arrivals; p.off_rec = L.rec; p.off_slots = L.slots;
+    // (the merging wave addresses the partials with 32-bit offsets)
+    if (need >= (int64_t)1 << 31) return M355_ERR_UNSUPPORTED;
+    { static const int in_kernel = dev_env_int("M355_MERGE_IN_KERNEL", 0);   // (dev build, 1: last-arriver merge inside the attention launch, A/B)
+      p.merge_in_kernel = use_mfma() && in_kernel; }
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.nwh = nwh; p.max_ranges = L.max_ranges; p.scale_log2 = scale * kLog2e;
     p.stamps = M355_STREAM_STAMPS;
     { static const int rot = dev_env_int("M355_STREAM_ROT", 1);    // (dev build, 0: no head rotation, for A/B)
@@ -719,8 +727,10 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
     if (use_mfma()) {
         const int rc = launch_stream_mfma(p, D, G, token_capacity, st, dev_env_set("M355_STREAM_STAMP"), f16);
         if (rc != M355_OK) return rc;
-        if (f16) { if (D == 64) launch_merge<64, true>(p, st); else launch_merge<128, true>(p, st); }
-        else { if (D == 64) launch_merge<64>(p, st); else launch_merge<128>(p, st); }
+        if (!p.merge_in_kernel) {
+            if (f16) { if (D == 64) launch_merge<64, true>(p, st); else launch_merge<128, true>(p, st); }
+            else { if (D == 64) launch_merge<64>(p, st); else launch_merge<128>(p, st); }
+        }
         return check_launch();
     }
 #ifdef M355_DEV

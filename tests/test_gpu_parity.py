@@ -609,6 +609,8 @@ def test_random_configurations_sweep():
         runs += [(x, {"M355_LIB_PATH": "dev", "M355_DECODE_SHARE": s}) for s in ("0", "1") for x in ([], ["f16"])]
         # ... and the dev-only 64-rows-per-wave prefill kernel on every head_dim-128 extend (csrc/prefill_wg2.hip)
         runs += [([], {"M355_LIB_PATH": "dev", "M355_PREFILL_RT": "2"})]
+        # ... and the dev-only in-kernel merge of the range kernel (decode_mfma.hip: last arriver merges; one and two levels)
+        runs += [(x, {"M355_LIB_PATH": "dev", "M355_DECODE_SHARE": "0", "M355_MERGE_IN_KERNEL": "1"}) for x in ([], ["f16"])]
     for extra, env in runs:
         r = subprocess.run([sys.executable, tool, "1", "5"] + extra, capture_output=True, text=True, timeout=110,
                            env=dict(os.environ, **env))
