@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--fixed-len", type=int, default=0, help="experiment: every request has this length (with --batch)")
     ap.add_argument("--batch", type=int, default=0, help="experiment: batch size for --fixed-len")
     ap.add_argument("--layers", type=int, default=0, help="experiment: number of layers (distinct KV pools)")
+    ap.add_argument("--row-pad", type=int, default=-1, help="experiment: KV row padding in elements (0 = the reference's contiguous pools)")
     ap.add_argument("--len-scale", type=int, default=1, help="experiment: every length x this (SURVEY 8d cfg2 'long' variant: 8)")
     args = ap.parse_args()
 
@@ -96,7 +97,7 @@ def main():
     rehearse = os.environ.get("M355_BENCH_REHEARSE") == "1"            # dev: all ranks on cuda:0 over gloo (one-GPU box)
     if rehearse:
         local_rank = 0
-    experiment = bool(args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1)
+    experiment = bool(args.heads or args.copies or args.fixed_len or args.layers or args.len_scale > 1 or args.row_pad >= 0)
     measured = None
     if world == 1 and not experiment and not args.no_pmc:
         note(0, "HBM traffic: two rocprofv3 --pmc child passes of the headline leg")
@@ -129,7 +130,7 @@ def main():
         L = args.layers
     B = len(lens0)
     case = W.decode_case(dev, Hq, Hkv, D, lens0, L, ps=ps, room=args.warmup + args.steps + 16, seed=1234 + rank,
-                         device_free_list=os.environ.get("M355_DEVICE_FREE_LIST", "1") != "0")
+                         row_pad=args.row_pad if args.row_pad >= 0 else None, device_free_list=os.environ.get("M355_DEVICE_FREE_LIST", "1") != "0")
     batch, backend = case.batch, case.backend
 
     def fence():
