@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define M355_VERSION 300 /* 0.3.0: m355_decode_plan takes pt_cols; M355_NO_SLOT; M355_PLAN_ERROR_WORD; m355_comm_free pools */
+#define M355_VERSION 310 /* 0.3.1: the decode plan / workspace calls take the pools' row pitch (kernel choice follows the pool layout) */
 
 enum {
     M355_OK = 0,
@@ -135,8 +135,10 @@ int m355_decode_prepare_ring(int32_t *page_table, int64_t pt_row_stride, int32_t
  * Self-contained form, for callers without a per-forward hook: the call lays out the decode plan (m355_decode_plan, for
  * B * max_seq_len_hint tokens) inside `workspace` and then runs m355_decode_attn_planned over it - two small launches
  * more per call than the planned form, which shares one plan between all layers of a forward.
- * max_seq_len_hint must be >= max(seq_lens); workspace: m355_decode_workspace_bytes, 256-byte aligned. */
-int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D, int32_t max_seq_len_hint);
+ * max_seq_len_hint must be >= max(seq_lens); workspace: m355_decode_workspace_bytes (same pool_row_stride as the call),
+ * 256-byte aligned. */
+int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D, int32_t max_seq_len_hint,
+                                    int64_t pool_row_stride);
 int m355_decode_attn(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
                      int64_t pool_row_stride, const int32_t *page_table, int64_t pt_row_stride, const int64_t *page_table_ids,
                      const int64_t *seq_lens, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
@@ -154,12 +156,20 @@ int m355_decode_attn(const void *q, int64_t q_row_stride, const void *k_pool, co
  *                             longer than pt_cols * page_size tokens is attended up to the row's end only - no look-up
  *                             ever leaves its row - and, like a request the capacity cut, it is left out of the fused
  *                             KV store (m355_decode_store_attn_planned writes nothing for it).
- *   m355_decode_attn_planned  once per layer, after m355_kv_store; same B, Hq, Hkv, D, token_capacity as the plan.
+ *                             pool_row_stride = the row pitch (elements; 0 = contiguous [S, Hkv, D]) of the pools the
+ *                             attention calls over this plan will read: which kernel serves the batch - and with it the
+ *                             plan's format - also follows the pool layout (contiguous power-of-two rows of the
+ *                             reference, memory/kvcache.py:24-35, pin a kv head to one address column; see
+ *                             csrc/decode_stream.hip share_mode).
+ *   m355_decode_attn_planned  once per layer, after m355_kv_store; same B, Hq, Hkv, D, token_capacity AND pool_row_stride
+ *                             as the plan (a plan is only valid for pools of the pitch it was made for).
  *                             workspace: m355_decode_planned_workspace_bytes bytes, fp32 partials. */
-int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity);
+int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity,
+                               int64_t pool_row_stride);
 int m355_decode_plan(const int64_t *seq_lens, const int64_t *page_table_ids, const int32_t *page_table,
                      int64_t pt_row_stride, int32_t pt_cols, int32_t B, int32_t page_size, int32_t Hkv, int32_t D,
-                     int32_t G, int64_t token_capacity, void *plan, int64_t plan_bytes, void *stream);
+                     int32_t G, int64_t token_capacity, int64_t pool_row_stride, void *plan, int64_t plan_bytes,
+                     void *stream);
 /* The plan's int32 word M355_PLAN_ERROR_WORD is 0 after m355_decode_plan.  The single-launch decode kernel hands
  * partial results of requests cut by a workgroup boundary from one workgroup to another; every wait in it is bounded,
  * and a wait that runs out (never seen on hardware; it would take another tenant holding CUs for seconds) sets this
@@ -168,7 +178,7 @@ int m355_decode_plan(const int64_t *seq_lens, const int64_t *page_table_ids, con
  * mi355_attn exposes it as DecodePlan.error() / MI355AttnBackend.check(). */
 #define M355_PLAN_ERROR_WORD 6
 int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
-                                            int64_t token_capacity);
+                                            int64_t token_capacity, int64_t pool_row_stride);
 int m355_decode_attn_planned(const void *q, int64_t q_row_stride, const void *k_pool, const void *v_pool,
                              int64_t pool_row_stride, void *plan, void *out, int64_t o_row_stride, int32_t B, int32_t Hq,
                              int32_t Hkv, int32_t D, float scale, int64_t token_capacity, void *workspace,
@@ -192,7 +202,7 @@ int m355_decode_store_attn_planned(const void *q, int64_t q_row_stride, const vo
  * torch); same arguments minus the workspace, same pools and the same output bit for bit.  The fp32 partials live in a
  * device array inside the library instead - M355_STATIC_SCRATCH_BYTES per GPU the library has run on, held until the
  * process ends - and the call allocates and frees nothing.  A batch whose
- * m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity) exceeds that limit is refused with
+ * m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity, pool_row_stride) exceeds that limit is refused with
  * M355_ERR_SCRATCH_LIMIT (nothing is launched); use the workspace form for it.  Every call on one GPU shares that
  * GPU's array: calls that overlap on one GPU (two streams, two threads) race - order them.  The first call on a
  * device looks the array's address up (hipGetSymbolAddress): make it outside graph capture. */

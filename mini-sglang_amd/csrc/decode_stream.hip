@@ -574,15 +574,23 @@ static inline int stream_rmin(int, int) { return mfma_rmin(); }
 // per-wave ranges + merge launch (decode_mfma.hip) serves the rest: small launches, and few long requests (thousands of
 // tokens per request and CU), where hundreds of pieces per request want the wide merge.  Plan, workspace and attention
 // calls all decide from the same (B, head shape, token_capacity); the dev build can force either with M355_DECODE_SHARE=0/1.
+// A third condition looks at the POOL: in a pool whose token rows are a multiple of 1 KiB apart (the reference's contiguous
+// [S, Hkv, D] rows, memory/kvcache.py:24-35, for every power-of-two head shape) one kv head's bytes of ALL tokens share
+// address bits 7..9, and a CU that streams only that 128-byte column (head_dim 64) runs well below its rate: the share
+// kernel, one kv head per workgroup, takes 34.5 us on configs[1] there against 29.3 on rows padded by 128 bytes, while the
+// range kernel - eight waves of a CU on eight different heads - takes 31.8 on either (profiles/r03_contiguous_ab.txt; at
+// head_dim 128, 256-byte columns, the two are within 3 % of each other, either way).  Such pools go to the range kernel.
 constexpr int kShareSpan = 8;
 constexpr int64_t kShareMinBytes = 512 * 1024;
-static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
+static inline int64_t pool_pitch(int32_t Hkv, int32_t D, int64_t pool_row_stride) { return pool_row_stride > 0 ? pool_row_stride : (int64_t)Hkv * D; }
+static bool share_mode(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity, int64_t pool_row_stride) {
     if (!use_mfma()) return false;
     const ShareShape sh = share_shape(Hkv, D, G);
     if (!sh.ok) return false;
     static const int forced = dev_env_int("M355_DECODE_SHARE", -1);
     if (forced >= 0) return forced != 0;
-    return (int64_t)B * kShareSpan >= sh.nb && token_capacity * 4 * D >= (int64_t)sh.nb * kShareMinBytes;
+    const bool pinned_columns = D == 64 && Hkv > 1 && (pool_pitch(Hkv, D, pool_row_stride) * 2) % 1024 == 0;
+    return (int64_t)B * kShareSpan >= sh.nb && token_capacity * 4 * D >= (int64_t)sh.nb * kShareMinBytes && !pinned_columns;
 }
 
 }  // namespace m355
@@ -596,23 +604,23 @@ extern "C" int m355dbg_set_stream_stamp_buffer(void* dev_ptr) {   // dev build o
 }
 #endif
 
-extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity) {
+extern "C" int64_t m355_decode_plan_bytes(int32_t B, int32_t Hkv, int32_t D, int32_t G, int64_t token_capacity, int64_t pool_row_stride) {
     if (B <= 0 || Hkv <= 0 || token_capacity <= 0) return 0;
-    if (share_mode(B, Hkv, D, G, token_capacity))
+    if (share_mode(B, Hkv, D, G, token_capacity, pool_row_stride))
         return share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G).ints * (int64_t)sizeof(int32_t);
     return plan_layout(B, stream_nwh(Hkv, D, G, token_capacity), Hkv, token_capacity).ints * (int64_t)sizeof(int32_t);
 }
 
 extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_table_ids, const int32_t* page_table,
                                 int64_t pt_row_stride, int32_t pt_cols, int32_t B, int32_t page_size, int32_t Hkv, int32_t D, int32_t G,
-                                int64_t token_capacity, void* plan, int64_t plan_bytes, void* stream) {
+                                int64_t token_capacity, int64_t pool_row_stride, void* plan, int64_t plan_bytes, void* stream) {
     if (B == 0) return M355_OK;
     if (!seq_lens || !page_table_ids || !page_table || !plan || B < 0 || page_size <= 0 || Hkv <= 0 || token_capacity <= 0 ||
         pt_row_stride <= 0 || pt_cols <= 0 || pt_cols > pt_row_stride)
         return M355_ERR_INVALID_ARG;
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
-    if (token_capacity > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
-    if (share_mode(B, Hkv, D, G, token_capacity)) {
+    if (token_capacity > 0x7fffffffLL / 2 || pool_row_stride < 0) return M355_ERR_INVALID_ARG;
+    if (share_mode(B, Hkv, D, G, token_capacity, pool_row_stride)) {
         const ShareLayout SL = share_layout(B, share_shape(Hkv, D, G).nb, Hkv, token_capacity, D, G);
         if (plan_bytes < SL.ints * (int64_t)sizeof(int32_t) || ((uintptr_t)plan & 15)) return M355_ERR_WORKSPACE;
         return launch_share_plan(seq_lens, page_table_ids, page_table, pt_row_stride, pt_cols, B, page_size, Hkv, D, G, token_capacity,
@@ -632,9 +640,9 @@ extern "C" int m355_decode_plan(const int64_t* seq_lens, const int64_t* page_tab
 }
 
 extern "C" int64_t m355_decode_planned_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
-                                                       int64_t token_capacity) {
+                                                       int64_t token_capacity, int64_t pool_row_stride) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return 0;
-    if (share_mode(B, Hkv, D, Hq / Hkv, token_capacity)) return 0;      // single launch: partials never leave LDS (hand-offs ride in the plan)
+    if (share_mode(B, Hkv, D, Hq / Hkv, token_capacity, pool_row_stride)) return 0;      // single launch: partials never leave LDS (hand-offs ride in the plan)
     const PlanLayout L = plan_layout(B, stream_nwh(Hkv, D, Hq / Hkv, token_capacity), Hkv, token_capacity);
     const int64_t n_partials = (int64_t)L.max_ranges + B;      // every range boundary and request adds at most one
     return n_partials * Hq * (D + 2) * (int64_t)sizeof(float);
@@ -687,7 +695,7 @@ static int decode_attn_planned_impl(const void* q, int64_t q_row_stride, const v
         return M355_ERR_INVALID_ARG;
     if (pool_row_stride == 0) pool_row_stride = (int64_t)Hkv * D;
     if (pool_row_stride < (int64_t)Hkv * D || pool_row_stride % 8) return M355_ERR_INVALID_ARG;
-    if (share_mode(B, Hkv, D, G, token_capacity)) {
+    if (share_mode(B, Hkv, D, G, token_capacity, pool_row_stride)) {
         const ShareShape sh = share_shape(Hkv, D, G);
         const ShareLayout SL = share_layout(B, sh.nb, Hkv, token_capacity, D, G);
         ShareParams sp;
@@ -776,7 +784,7 @@ extern "C" int m355_decode_store_attn_planned_static(const void* q, int64_t q_ro
         (v_row_stride % 8) || (((uintptr_t)k_new | (uintptr_t)v_new) & 15))
         return M355_ERR_INVALID_ARG;
     if (B < 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || token_capacity <= 0) return M355_ERR_INVALID_ARG;
-    if (m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity) > (int64_t)M355_STATIC_SCRATCH_BYTES)
+    if (m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity, pool_row_stride) > (int64_t)M355_STATIC_SCRATCH_BYTES)
         return M355_ERR_SCRATCH_LIMIT;
     void* ws = static_scratch();
     if (!ws) return M355_ERR_LAUNCH;
@@ -806,10 +814,12 @@ extern "C" int m355_decode_store_attn_planned(const void* q, int64_t q_row_strid
 // ------------------------------------------------------------------------------------------------
 static inline int64_t up256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-extern "C" int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D, int32_t max_seq_len_hint) {
+extern "C" int64_t m355_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D, int32_t max_seq_len_hint,
+                                               int64_t pool_row_stride) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || max_seq_len_hint <= 0 || Hq % Hkv) return 0;
     const int64_t cap = (int64_t)B * max_seq_len_hint;
-    return up256(m355_decode_plan_bytes(B, Hkv, D, Hq / Hkv, cap)) + up256(m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap));
+    return up256(m355_decode_plan_bytes(B, Hkv, D, Hq / Hkv, cap, pool_row_stride)) +
+           up256(m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap, pool_row_stride));
 }
 
 extern "C" int m355_decode_attn(const void* q, int64_t q_row_stride, const void* k_pool, const void* v_pool,
@@ -823,13 +833,14 @@ extern "C" int m355_decode_attn(const void* q, int64_t q_row_stride, const void*
     if (cap > 0x7fffffffLL / 2) return M355_ERR_INVALID_ARG;
     const int G = Hq / Hkv;
     if ((D != 64 && D != 128) || (G != 1 && G != 2 && G != 4 && G != 8)) return M355_ERR_UNSUPPORTED;
-    const int64_t pb = up256(m355_decode_plan_bytes(B, Hkv, D, G, cap));
-    const int64_t wb = up256(m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap));
+    if (pool_row_stride < 0) return M355_ERR_INVALID_ARG;
+    const int64_t pb = up256(m355_decode_plan_bytes(B, Hkv, D, G, cap, pool_row_stride));
+    const int64_t wb = up256(m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap, pool_row_stride));
     if (!workspace || workspace_bytes < pb + wb || ((uintptr_t)workspace & 255)) return M355_ERR_WORKSPACE;
     // (this form is not told the table's width: its row stride bounds the look-ups, so they never leave the request's row)
     if (pt_row_stride <= 0 || pt_row_stride > 0x7fffffffLL) return M355_ERR_INVALID_ARG;
     const int rc = m355_decode_plan(seq_lens, page_table_ids, page_table, pt_row_stride, (int32_t)pt_row_stride, B, page_size, Hkv, D, G, cap,
-                                    workspace, pb, stream);
+                                    pool_row_stride, workspace, pb, stream);
     if (rc != M355_OK) return rc;
     return m355_decode_attn_planned(q, q_row_stride, k_pool, v_pool, pool_row_stride, workspace, out, o_row_stride, B, Hq, Hkv, D, scale,
                                     cap, (char*)workspace + pb, wb, dtype, stream);

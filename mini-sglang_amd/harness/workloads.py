@@ -78,7 +78,7 @@ def decode_kernel_name(c: SimpleNamespace) -> str:
     """Which attention kernel the library runs for this batch (it decides from B and the head shape alone): the
     single-launch share kernel needs no partials workspace, the per-wave-range kernel + merge does."""
     cap = sum(c.batch.seq_lens_host)
-    if ops.decode_planned_workspace_bytes(c.B, c.Hq, c.Hkv, c.D, cap) == 0:
+    if ops.decode_planned_workspace_bytes(c.B, c.Hq, c.Hkv, c.D, cap, ops.pool_pitch(*c.kv.get_kv_cache(0))) == 0:
         return "m355::decode_share_kernel"
     return "m355::decode_mfma_kernel (+ m355::stream_merge_kernel)"
 
@@ -90,7 +90,7 @@ def time_decode_launches(c: SimpleNamespace, reps: int = 20, fused: bool = True)
     md = c.backend.forward_metadata
     assert md is not None and md.decode and md.plan is not None, "run decode_step first"
     lens = list(c.batch.seq_lens_host)
-    ws = c.backend._ws(ops.decode_planned_workspace_bytes(c.B, c.Hq, c.Hkv, c.D, md.plan.capacity), c.dev)
+    ws = c.backend._ws(ops.decode_planned_workspace_bytes(c.B, c.Hq, c.Hkv, c.D, md.plan.capacity, md.plan.pitch), c.dev)
     if ws is None:
         ws = torch.empty(16, dtype=torch.uint8, device=c.dev)
     pools = [c.kv.get_kv_cache(l) for l in range(c.L)]

@@ -45,14 +45,14 @@ SIGNATURES = {
     "m355_page_ring_push": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
     "m355_decode_prepare_ring": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                            c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
-    "m355_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "m355_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int64]),
     "m355_decode_attn": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
                                    c_void_p, c_int64, c_int32, c_void_p]),
-    "m355_decode_plan_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
+    "m355_decode_plan_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64, c_int64]),
     "m355_decode_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                   c_int64, c_void_p, c_int64, c_void_p]),
-    "m355_decode_planned_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
+                                   c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "m355_decode_planned_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64, c_int64]),
     "m355_decode_attn_planned": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                            c_int32, c_int32, c_int32, c_float, c_int64, c_void_p, c_int64, c_int32,
                                            c_void_p]),

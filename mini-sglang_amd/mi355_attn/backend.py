@@ -161,14 +161,15 @@ class MI355AttnBackend:
         if md.plan is None:                        # first layer of this forward: lay the token stream out once
             cap = max(self._plan_key[1], int(self.decode_capacity_hint))
             md.plan = ops.decode_plan(batch.page_manager.page_table, batch.page_table_ids, batch.seq_lens,
-                                      self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf)
+                                      self.page_size, Hq, Hkv, D, cap, buf=self._plan_buf,
+                                      pool_row_stride=ops.pool_pitch(k_pool, v_pool))
             if self.buffers_pinned and md.plan.buf is not self._plan_buf:
                 raise ops._lib.MI355AttnError("MI355AttnBackend: a captured graph pins the plan buffer; this forward needs a "
                                               "bigger one (release the graph first: GraphedDecode.release())")
             self._plan_buf = md.plan.buf
         ws = md.ws                                 # sized once per forward (same shape in every layer)
         if ws is None or md.ws_key != (B, Hq, Hkv, D):
-            ws = md.ws = self._ws(max(256, ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity)), q.device)
+            ws = md.ws = self._ws(max(256, ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, md.plan.capacity, md.plan.pitch)), q.device)
             md.ws_key = (B, Hq, Hkv, D)
         o = ops.decode_attn_planned(q.reshape(B, Hq * D), k_pool, v_pool, md.plan, Hq, workspace=ws,
                                     k_new=k if fuse else None, v_new=v if fuse else None)

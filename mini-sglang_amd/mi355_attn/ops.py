@@ -171,8 +171,8 @@ def decode_prepare_ring(page_table: torch.Tensor, rows: torch.Tensor, seq_lens: 
     return trio[0], trio[1], trio[2]
 
 
-def decode_workspace_bytes(B: int, Hq: int, Hkv: int, D: int, max_seq_len: int) -> int:
-    return int(_lib.load().m355_decode_workspace_bytes(B, Hq, Hkv, D, max_seq_len))
+def decode_workspace_bytes(B: int, Hq: int, Hkv: int, D: int, max_seq_len: int, pool_row_stride: int = 0) -> int:
+    return int(_lib.load().m355_decode_workspace_bytes(B, Hq, Hkv, D, max_seq_len, pool_row_stride))
 
 
 def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, page_table: torch.Tensor,
@@ -196,7 +196,7 @@ def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, pag
         out = torch.empty((B, Hq * D), dtype=q.dtype, device=q.device)
     if scale is None:
         scale = float(D) ** -0.5          # SDPA default: the reference never passes layer.scale on
-    need = decode_workspace_bytes(B, Hq, Hkv, D, max_seq_len)
+    need = decode_workspace_bytes(B, Hq, Hkv, D, max_seq_len, pool_pitch(k_pool, v_pool))
     if workspace is None or workspace.numel() * workspace.element_size() < need or workspace.data_ptr() % 256:
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
     ws_bytes = workspace.numel() * workspace.element_size()
@@ -210,10 +210,10 @@ def decode_attn(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, pag
 
 
 class DecodePlan:
-    """Per-forward decode plan (device buffer + the sizes it was built for)."""
+    """Per-forward decode plan (device buffer + the sizes and the pool row pitch it was built for)."""
 
-    def __init__(self, buf, B, Hkv, D, G, capacity):
-        self.buf, self.B, self.Hkv, self.D, self.G, self.capacity = buf, B, Hkv, D, G, capacity
+    def __init__(self, buf, B, Hkv, D, G, capacity, pitch):
+        self.buf, self.B, self.Hkv, self.D, self.G, self.capacity, self.pitch = buf, B, Hkv, D, G, capacity, pitch
 
     def error(self) -> int:
         """The plan's give-up word (M355_PLAN_ERROR_WORD): non-zero when a bounded cross-workgroup wait of the single-launch
@@ -224,25 +224,29 @@ class DecodePlan:
 
 def decode_plan(page_table: torch.Tensor, page_table_ids: torch.Tensor, seq_lens: torch.Tensor, page_size: int,
                 num_heads: int, num_kv_heads: int, head_dim: int, token_capacity: int,
-                buf: torch.Tensor | None = None) -> DecodePlan:
-    """Build the per-forward decode plan on the device (no host sync).  token_capacity >= sum(seq_lens)."""
+                buf: torch.Tensor | None = None, pool_row_stride: int = 0) -> DecodePlan:
+    """Build the per-forward decode plan on the device (no host sync).  token_capacity >= sum(seq_lens).
+    pool_row_stride: row pitch (elements) of the KV pools the attention calls will read, pool_pitch(k_pool, v_pool);
+    0 = contiguous [S, Hkv, D] rows.  The kernel choice - and the plan's format - follow the pool layout, so a plan is
+    only valid for pools of that pitch (decode_attn_planned checks)."""
     lib = _lib.load()
     for n, t in (("page_table", page_table), ("page_table_ids", page_table_ids), ("seq_lens", seq_lens)):
         require_cuda(t, n)
     assert page_table.dtype == torch.int32 and page_table_ids.dtype == torch.int64 and seq_lens.dtype == torch.int64
     B = seq_lens.numel()
     G = num_heads // num_kv_heads
-    need = int(lib.m355_decode_plan_bytes(B, num_kv_heads, head_dim, G, token_capacity))
+    pitch = int(pool_row_stride) or num_kv_heads * head_dim
+    need = int(lib.m355_decode_plan_bytes(B, num_kv_heads, head_dim, G, token_capacity, pitch))
     if buf is None or buf.numel() * buf.element_size() < need:
         buf = torch.empty(need, dtype=torch.uint8, device=seq_lens.device)
     check(lib.m355_decode_plan(seq_lens.data_ptr(), page_table_ids.data_ptr(), page_table.data_ptr(),
                                page_table.stride(0), page_table.shape[1], B, page_size, num_kv_heads, head_dim, G, token_capacity,
-                               buf.data_ptr(), buf.numel() * buf.element_size(), current_stream()), "m355_decode_plan")
-    return DecodePlan(buf, B, num_kv_heads, head_dim, G, token_capacity)
+                               pitch, buf.data_ptr(), buf.numel() * buf.element_size(), current_stream()), "m355_decode_plan")
+    return DecodePlan(buf, B, num_kv_heads, head_dim, G, token_capacity, pitch)
 
 
-def decode_planned_workspace_bytes(B: int, Hq: int, Hkv: int, D: int, token_capacity: int) -> int:
-    return int(_lib.load().m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity))
+def decode_planned_workspace_bytes(B: int, Hq: int, Hkv: int, D: int, token_capacity: int, pool_row_stride: int = 0) -> int:
+    return int(_lib.load().m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, token_capacity, pool_row_stride))
 
 
 STATIC_SCRATCH_BYTES = 8 * 1024 * 1024        # M355_STATIC_SCRATCH_BYTES (include/mi355attn.h)
@@ -265,6 +269,9 @@ def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Ten
     if (B, Hkv, D, Hq // Hkv) != (plan.B, plan.Hkv, plan.D, plan.G):
         raise _lib.MI355AttnError("decode_attn_planned: plan was built for a different batch or head shape")
     pitch = pool_pitch(k_pool, v_pool)
+    if pitch != plan.pitch:
+        raise _lib.MI355AttnError(f"decode_attn_planned: the plan was built for pools of row pitch {plan.pitch}, these have {pitch} "
+                                  "(pass pool_row_stride=pool_pitch(k_pool, v_pool) to decode_plan)")
     q2 = q.view(B, Hq * D)
     if q2.stride(1) != 1:
         q2 = q2.contiguous()
@@ -273,7 +280,7 @@ def decode_attn_planned(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Ten
     if scale is None:
         scale = float(D) ** -0.5
     if workspace is None and not static_scratch:   # (a caller's workspace is size-checked by the library itself)
-        workspace = torch.empty(decode_planned_workspace_bytes(B, Hq, Hkv, D, plan.capacity), dtype=torch.uint8,
+        workspace = torch.empty(decode_planned_workspace_bytes(B, Hq, Hkv, D, plan.capacity, pitch), dtype=torch.uint8,
                                 device=q.device)
     if static_scratch and k_new is None:
         raise _lib.MI355AttnError("decode_attn_planned: static_scratch is the fused-store form (pass k_new / v_new)")

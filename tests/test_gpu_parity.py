@@ -293,6 +293,15 @@ def test_decode_attn_split_and_merge(Hq, Hkv, D, ps):
         np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=BF16_RTOL, atol=BF16_ATOL, err_msg=f"planned cap={cap}")
 
 
+def _padded(pool, pad=64):
+    """The same [S, Hkv, D] pool with `pad` unused elements behind every token row (mi355_attn.KVCache's layout: the
+    share kernel's home; contiguous power-of-two rows at head_dim 64 go to the range kernel, csrc/decode_stream.hip)."""
+    S, Hkv, D = pool.shape
+    full = torch.zeros((S, Hkv * D + pad), dtype=pool.dtype, device=pool.device)
+    full[:, :Hkv * D] = pool.reshape(S, Hkv * D)
+    return full[:, :Hkv * D].unflatten(1, (Hkv, D))
+
+
 def _gpu_decode_reference(q, kp, vp, table, rows, lens, ps, Hq):
     """torch fp32 on the GPU, one request at a time, same gather as the reference backend."""
     B = len(lens)
@@ -377,16 +386,24 @@ def test_decode_planned_more_ranges_than_waves():
         n = -(-l // ps)
         table[b, :n] = perm[off:off + n]
         off += n
-    kp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)
-    vp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16)
+    kp = _padded(torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16))
+    vp = _padded(torch.randn((npages * ps, Hkv, D), generator=g, device=DEV).to(torch.bfloat16))
+    pitch = ops.pool_pitch(kp, vp)
     q = (torch.randn((B, Hq * D), generator=g, device=DEV) * 3).to(torch.bfloat16)
     dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
     ref = _gpu_decode_reference(q, kp, vp, dt, list(range(B)), lens, ps, Hq)
-    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens), pool_row_stride=pitch)
     o = ops.decode_attn_planned(q, kp, vp, plan, Hq)
     assert torch.allclose(o.float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
-    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens)) == 0          # the share kernel, 3-4 publishers per merger
+    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens), pitch) == 0   # the share kernel, 3-4 publishers per merger
     assert plan.error() == 0
+    # the same batch on contiguous pools (the reference's layout): several ranges per wave of the range kernel
+    kc, vc = kp.contiguous(), vp.contiguous()
+    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens), 0) > 0
+    plan_c = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    assert torch.allclose(ops.decode_attn_planned(q, kc, vc, plan_c, Hq).float(), ref, rtol=BF16_RTOL, atol=BF16_ATOL)
+    with pytest.raises(Exception, match="pitch"):                                     # a plan is made for ONE pool layout
+        ops.decode_attn_planned(q, kp, vp, plan_c, Hq)
 
 
 def test_decode_attn_softmax_spike():
@@ -574,14 +591,21 @@ def test_decode_cfg2_full_size_properties():
         n = -(-l // ps)
         table[b, :n] = perm[off:off + n].to(torch.int32)
         off += n
-    kp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
-    vp = torch.randn((npages * ps, Hkv, D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    # rows padded as mi355_attn.KVCache pads them (the headline's layout: the share kernel), and the reference's contiguous
+    # rows (head_dim 64: the range kernel + merge)
+    kp = _padded(torch.randn((npages * ps, Hkv, D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16))
+    vp = _padded(torch.randn((npages * ps, Hkv, D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16))
+    pitch = ops.pool_pitch(kp, vp)
     q = torch.randn((B, Hq * D), generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
     dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
     outs = [ops.decode_attn(q, kp, vp, dt, dr, dl, ps, Hq, hint).float() for hint in (max(lens), 2 * max(lens))]
-    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens))
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens), pool_row_stride=pitch)
     outs.append(ops.decode_attn_planned(q, kp, vp, plan, Hq).float())
-    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens)) == 0 and plan.error() == 0     # the share kernel, no give-up
+    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens), pitch) == 0 and plan.error() == 0     # the share kernel, no give-up
+    kc, vc = kp.contiguous(), vp.contiguous()
+    assert ops.decode_planned_workspace_bytes(B, Hq, Hkv, D, sum(lens), 0) > 0                            # contiguous: ranges + merge
+    outs.append(ops.decode_attn_planned(q, kc, vc, ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, sum(lens)), Hq).float())
+    outs.append(ops.decode_attn(q, kc, vc, dt, dr, dl, ps, Hq, max(lens)).float())
     for o in outs[1:]:
         assert torch.allclose(o, outs[0], rtol=BF16_RTOL, atol=BF16_ATOL)
     # torch fp32 reference on the GPU, one sequence at a time (same gather as the reference backend)

@@ -31,6 +31,19 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b(m355_[a-z0-9_]+)\s*\(", text)))
 
 
+def _declared_arities():
+    """name -> number of parameters, from the prototypes in include/*.h"""
+    text = ""
+    for header in ("mi355attn.h", "mi355tp.h"):
+        with open(os.path.join(REPO, "include", header)) as f:
+            text += re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    out = {}
+    for name, args in re.findall(r"\b(m355_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        args = args.strip()
+        out[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
 def test_library_exports_every_declared_symbol():
     from mi355_attn import _lib
     declared = _declared_symbols()
@@ -39,10 +52,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mi355attn.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
+    arity = _declared_arities()
+    assert sorted(arity) == declared
+    for name, (_, argtypes) in _lib.SIGNATURES.items():             # an extra or missing argument is a silent stack shift in ctypes
+        assert len(argtypes) == arity[name], f"{name}: header has {arity[name]} parameters, the ctypes table {len(argtypes)}"
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r"\b(m355[a-z]*_[a-z0-9_]+)\b", out))
     assert exported == set(declared), "the product library exports exactly what include/*.h declares (no dev symbols)"
-    assert lib.m355_version() == 300
+    assert lib.m355_version() == 310
     assert b"workspace" in lib.m355_strerror(-3)
 
 

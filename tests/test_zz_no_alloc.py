@@ -30,30 +30,39 @@ def _case(B, Hq, Hkv, D, ps, lens, seed):
     return table, kp, vp, qkv
 
 
-def _run_both(ops, lib, B, Hq, Hkv, D, ps, lens, seed):
+def _dev_pool(pool, pad):
+    """[S, Hkv, D] on the device with `pad` unused elements behind every token row (0: contiguous, the reference's layout)."""
+    S, Hkv, D = pool.shape
+    full = torch.zeros((S, Hkv * D + pad), dtype=pool.dtype, device=DEV)
+    full[:, :Hkv * D] = pool.reshape(S, Hkv * D).to(DEV)
+    return full[:, :Hkv * D].unflatten(1, (Hkv, D))
+
+
+def _run_both(ops, lib, B, Hq, Hkv, D, ps, lens, seed, pad=0):
     from mi355_attn._lib import current_stream
     table, kp, vp, qkv = _case(B, Hq, Hkv, D, ps, lens, seed)
+    pitch = Hkv * D + pad
     dqkv = qkv.to(DEV)
     q, k, v = dqkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)                 # strided views of the packed projection
     dt, dr, dl = table.to(DEV), torch.arange(B, device=DEV), torch.tensor(lens, device=DEV)
     cap = sum(lens)
-    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, cap)
+    plan = ops.decode_plan(dt, dr, dl, ps, Hq, Hkv, D, cap, pool_row_stride=pitch)
     # workspace form
-    kp1, vp1 = kp.to(DEV), vp.to(DEV)
-    need = int(lib.m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap))
+    kp1, vp1 = _dev_pool(kp, pad), _dev_pool(vp, pad)
+    need = int(lib.m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap, pitch))
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
     o1 = torch.full((B, Hq * D), 7.0, dtype=torch.bfloat16, device=DEV)
     rc = lib.m355_decode_store_attn_planned(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                            kp1.data_ptr(), vp1.data_ptr(), 0, plan.buf.data_ptr(), o1.data_ptr(), o1.stride(0),
+                                            kp1.data_ptr(), vp1.data_ptr(), pitch, plan.buf.data_ptr(), o1.data_ptr(), o1.stride(0),
                                             B, Hq, Hkv, D, D ** -0.5, cap, ws.data_ptr(), need, 0, current_stream())
     assert rc == 0
     # allocation-free form: every buffer it touches exists before the call
-    kp2, vp2 = kp.to(DEV), vp.to(DEV)
+    kp2, vp2 = _dev_pool(kp, pad), _dev_pool(vp, pad)
     o2 = torch.full((B, Hq * D), -7.0, dtype=torch.bfloat16, device=DEV)
     torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
     rc = lib.m355_decode_store_attn_planned_static(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
-                                                   v.stride(0), kp2.data_ptr(), vp2.data_ptr(), 0, plan.buf.data_ptr(),
+                                                   v.stride(0), kp2.data_ptr(), vp2.data_ptr(), pitch, plan.buf.data_ptr(),
                                                    o2.data_ptr(), o2.stride(0), B, Hq, Hkv, D, D ** -0.5, cap, 0,
                                                    current_stream())
     assert rc == 0
@@ -74,7 +83,10 @@ def test_static_scratch_entry_equals_workspace_entry():
     # 1. cfg2-sized: B = 64 ragged, 1B head shape: served by the single-launch share kernel, which needs NO scratch (the
     #    partials of requests a share boundary cuts travel inside the plan buffer): need1 == 0, the array is not touched
     lens = [int(x) for x in rng.integers(64, 2049, size=64)]
-    need1 = _run_both(ops, lib, 64, 32, 8, 64, 16, lens, seed=1)
+    #    (rows padded as mi355_attn.KVCache pads them; on the reference's contiguous rows this shape goes to the range kernel: 1b)
+    need1 = _run_both(ops, lib, 64, 32, 8, 64, 16, lens, seed=1, pad=64)
+    need1b = _run_both(ops, lib, 64, 32, 8, 64, 16, lens, seed=1)
+    assert 0 < need1b <= ops.STATIC_SCRATCH_BYTES
     # 2. right after it, a SMALLER batch with another head shape (few requests per CU: per-wave ranges + merge, whose
     #    fp32 partials DO live in the scratch array): need2 > 0 - this is the case that exercises the array
     lens2 = [int(x) for x in rng.integers(1, 700, size=5)]
@@ -102,7 +114,7 @@ def test_static_scratch_entry_refuses_what_does_not_fit():
     from mi355_attn import _lib, ops
     lib = _lib.load()
     B, Hq, Hkv, D, cap = 16, 8, 1, 128, 1 << 21        # few, very long requests: thousands of fp32 partials
-    assert lib.m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap) > ops.STATIC_SCRATCH_BYTES
+    assert lib.m355_decode_planned_workspace_bytes(B, Hq, Hkv, D, cap, 0) > ops.STATIC_SCRATCH_BYTES
     x = torch.zeros(4096, dtype=torch.bfloat16, device=DEV)       # any valid, aligned device pointer: nothing is launched
     rc = lib.m355_decode_store_attn_planned_static(x.data_ptr(), Hq * D, x.data_ptr(), Hkv * D, x.data_ptr(), Hkv * D,
                                                    x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), x.data_ptr(), Hq * D, B, Hq,

@@ -49,7 +49,7 @@ lib = _lib.load()
 setter = lib.m355dbg_set_stream_stamp_buffer
 setter.argtypes = [ctypes.c_void_p]
 assert setter(stamps.data_ptr()) == 0
-plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens)) if STREAM else None
+plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens), pool_row_stride=ops.pool_pitch(*kv.get_kv_cache(0))) if STREAM else None
 ws = torch.empty(ops.decode_workspace_bytes(B, Hq, D, max_len, chunk), dtype=torch.uint8, device=dev)
 
 

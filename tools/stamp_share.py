@@ -50,7 +50,7 @@ lib = _lib.load()
 setter = lib.m355dbg_set_stream_stamp_buffer
 setter.argtypes = [ctypes.c_void_p]
 assert setter(stamps.data_ptr()) == 0
-plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens))
+plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens), pool_row_stride=ops.pool_pitch(*kv.get_kv_cache(0)))
 WS = int(plan.buf.view(torch.int32)[4].item())      # streaming waves per workgroup; the finishing wave is wave WS
 
 
