@@ -228,8 +228,9 @@ def extras(dev, tp, rank, rehearse, fence) -> dict:
         out["decode_contiguous_pool"] = guarded(W.decode_shape_report, dev, MODEL["Hq"], MODEL["Hkv"], MODEL["D"], W.cfg2_lengths(1), 16,
                                                 row_pad=0)
         if isinstance(out["decode_contiguous_pool"], dict):
-            out["decode_contiguous_pool"]["note"] = ("same batch and kernel as the headline, KVCache(row_pad=0): the reference's pool layout; "
-                                                     "the headline's padded rows cost 12.5 % more HBM per cached token on this shape")
+            out["decode_contiguous_pool"]["note"] = ("same batch as the headline on KVCache(row_pad=0), the reference's pool layout: the library serves "
+                                                     "head_dim-64 batches on contiguous power-of-two rows with the range kernel + merge (the share kernel "
+                                                     "takes 34.5 us there); the headline's padded rows cost 12.5 % more HBM per cached token on this shape")
     if tp in (1, 8):
         # cfg5: what ONE rank of Llama-3-70B at TP=8 streams - (8, 1, 128), every request 32 768 tokens (16 of the 80 layers)
         out["decode_cfg5_per_rank"] = {

@@ -113,3 +113,28 @@ def test_fused_oproj_refuses_bad_shapes():
             f([t[:16, :48] for t in x], [t[:, :48] for t in w])
     finally:
         f.close()
+
+
+def test_a_peer_that_never_arrives_cannot_pass_for_a_result():
+    """A world of two whose rank 1 is never launched: rank 0's bounded wait for rank 1's tile runs out (~1 s), the launch ENDS
+    (no hang), the error word is set and the rows of the tile hold NaN - a give-up is impossible to miss
+    (reference: dist.all_reduce would block, layers/linear.py:228-232).  The instance is not used again."""
+    from mi355_attn import _lib
+    from mi355_attn.tp import FusedRowParallel
+    T, N, K = 16, 64, 64                                         # one tile: one workgroup spins, for about a second
+    f = FusedRowParallel(N, t_cap=16, local_world=2, device_epoch=False)      # both ranks' buffers on this device
+    xs, ws, _ = _case(2, T, N, K, torch.bfloat16, seed=11)
+    out = torch.zeros((T, N), dtype=torch.bfloat16, device="cuda")
+    arr = f._entries(2)
+    arr[0].x, arr[0].x_row_stride, arr[0].w, arr[0].w_row_stride = xs[0].data_ptr(), xs[0].stride(0), ws[0].data_ptr(), ws[0].stride(0)
+    arr[0].out, arr[0].out_row_stride = out.data_ptr(), out.stride(0)
+    # n_ranks = 1 of world = 2: the multi-process form of the call, with only THIS rank's entry
+    rc = f._L.m355_oproj_allreduce(arr, 1, 2, T, N, K, f.t_cap, 1, None, f.error.data_ptr(), _lib.dtype_code(torch.bfloat16),
+                                   _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()                                     # returns: the wait is bounded
+    assert int(f.error.item()) == 1
+    assert torch.isnan(out.float()).all()
+    with pytest.raises(_lib.MI355AttnError, match="never arrived"):
+        f.check()
+    f.close()
