@@ -185,6 +185,26 @@ def reset_pools(runner):
     runner.page_manager.clear()
 
 
+REHEARSAL_NO_OVERLAP = 77       # exit code / stdout marker of a one-GPU rehearsal whose ranks were not run side by side
+
+
+def _rehearsal_check(runner) -> None:
+    """Two ranks rehearsing on ONE GPU (M355_BENCH_REHEARSE=1) with the fused row-parallel launches depend on the device
+    running both processes' kernels side by side: a rank's launch waits, bounded, for its peer's tile.  When the device
+    serves the processes one after the other instead, every such wait runs to its bound (seconds), the launches pile up on
+    the stream and the run takes minutes before anything reports it.  So the rehearsal - and only the rehearsal: with a GPU
+    per rank a wait only gives up when a peer is gone - looks at the give-up word after every decode step (a sync per step
+    is fine in a correctness run) and ends at the first one, saying so."""
+    fused = getattr(runner.model, "fused", None)
+    if fused is None or os.environ.get("M355_BENCH_REHEARSE") != "1":
+        return
+    torch.cuda.synchronize()
+    if int(fused.error.item()):
+        print("REHEARSAL_NO_OVERLAP: a fused row-parallel wait gave up - this device did not run the two ranks' kernels side by side",
+              flush=True)
+        os._exit(REHEARSAL_NO_OVERLAP)
+
+
 def three_phase(runner, prompts, cut_len: int, output_len: int, graph: bool = False):
     """prefill(cut) -> extend over the cached prefix -> decode; returns (final prefill logits, generated ids [B, output_len])."""
     ps = runner.page_size
@@ -201,6 +221,7 @@ def three_phase(runner, prompts, cut_len: int, output_len: int, graph: bool = Fa
         g = GraphedDecode(next_ids, batch, runner, output_len - 1)
         while g.taken < output_len - 1:
             g.next()
+            _rehearsal_check(runner)
         toks = torch.cat([next_ids.unsqueeze(1), g.tokens()], dim=1)
         g.release()
         return logits, toks
@@ -208,6 +229,7 @@ def three_phase(runner, prompts, cut_len: int, output_len: int, graph: bool = Fa
     for _ in range(output_len - 1):
         next_ids, _ = decode(next_ids, batch, runner)
         out.append(next_ids)
+        _rehearsal_check(runner)
     return logits, torch.stack(out, dim=1)
 
 

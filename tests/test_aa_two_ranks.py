@@ -98,9 +98,13 @@ def test_tp2_graphed_decode_with_the_fused_epilogue():
         pytest.skip("this device does not run two processes' kernels side by side (fused o_proj probe: bounded waits gave up)")
     two = _run_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                       "127.0.0.1", "--master-port", "29519", script] + args, env, 120)
-    if "fused row-parallel waits gave up: True" in two.stdout or "bounded wait gave up" in (two.stdout + two.stderr):
+    if ("REHEARSAL_NO_OVERLAP" in two.stdout or "fused row-parallel waits gave up: True" in two.stdout
+            or "bounded wait gave up" in (two.stdout + two.stderr)):
         # (the probe passed but a later wait still ran out: the same property of two processes sharing one GPU, reported by the
-        # error word / NaN rows / MI355AttnError as designed.  A hang, a wrong token WITHOUT a reported give-up or any other
+        # error word / NaN rows / MI355AttnError as designed.  The rehearsal looks at the give-up word after every decode step
+        # - bench_one_batch._rehearsal_check - because otherwise the launches that run to their bound pile up on the stream
+        # and the run dies of the time limit minutes before it can report anything: seen on about half of the boxes of round 3,
+        # both ranks then sat in the NEXT prefill's gloo all-reduce waiting for the stream to drain.  A hang, a wrong token WITHOUT a reported give-up or any other
         # failure is a failure of the multi-process path.)
         pytest.skip("a bounded wait gave up and was reported: the device stopped overlapping the two processes' kernels in this run")
     assert two.returncode == 0 and "correctness: PASS" in two.stdout, two.stdout[-2000:] + two.stderr[-2000:]
