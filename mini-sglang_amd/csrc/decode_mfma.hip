@@ -148,7 +148,11 @@ __device__ __forceinline__ void store_out_vec(uint16_t* op, const float (&acc)[V
 }
 
 template <int D, int G, int R, bool STAMP, bool F16 = false>
-__global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, const int slots_cap) {
+// (leading scalars: copies of the fields of `p` that address a wave's first record and slots; they are preloaded into SGPRs at
+// wave launch - Makefile: -amdgpu-kernarg-preload-count - so those first loads do not wait for a load of the argument block)
+__global__ __launch_bounds__(64) void decode_mfma_kernel(const int32_t* plan_hot, const int64_t off_rec_hot, const int64_t off_slots_hot,
+                                                         const int32_t Hkv_hot, const int32_t rot_hot, const StreamParams p,
+                                                         const int slots_cap) {
     using M = MG<D>;
     static_assert(G <= 16, "q heads of a group sit in the 16 columns of one MFMA");
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
@@ -163,12 +167,12 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
     const int lane = threadIdx.x;
     const int n = lane & 15;                             // q column / K row / d column, by operand
     const int kg = lane >> 4;                            // 16-lane group = k sub-block
-    const int w = blockIdx.x / p.Hkv;
+    const int w = blockIdx.x / Hkv_hot;
     // Workgroups go round-robin over the 8 XCDs, so with h = blockIdx % Hkv one XCD would stream one head only: one
     // 2*D-byte column of every Hkv*2*D-byte token row, i.e. a fixed value of the low address bits its L2 channels are
     // interleaved on.  Rotating the head every p.rot ranges lets every XCD touch every column (measured 35.3 -> 31.5 us).
-    const int h = (blockIdx.x + (p.rot > 0 ? w / p.rot : 0)) % p.Hkv;
-    const int32_t* plan = p.plan;
+    const int h = (blockIdx.x + (rot_hot > 0 ? w / rot_hot : 0)) % Hkv_hot;
+    const int32_t* plan = plan_hot;
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_pool) + (int64_t)h * M::ROWB;
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_pool) + (int64_t)h * M::ROWB;
     const int64_t row_bytes = p.row_elems * 2;
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const StreamParams p, c
 
     for (int r = w; r < p.max_ranges; r += p.nwh) {
         // ---- the record and (speculatively) the first slots in one round of loads
-        const int32_t* grec = plan + p.off_rec + (int64_t)r * kRec;
-        const int32_t* gslots = plan + p.off_slots + (int64_t)r * kRMax;
+        const int32_t* grec = plan + off_rec_hot + (int64_t)r * kRec;
+        const int32_t* gslots = plan + off_slots_hot + (int64_t)r * kRMax;
         int32_t rv = 0, sv[kSpec];
         if (lane < kRec) rv = grec[lane];
 #pragma unroll
@@ -579,22 +583,25 @@ static int launch_mfma(const StreamParams& p, int64_t cap, hipStream_t st, bool 
     const int lds = mfma_lds_bytes(D, G, R, slots_cap);
     if (lds > 64 * 1024) return M355_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(p.Hkv * p.nwh)), block(64);
+#define M355_HOT p.plan, p.off_rec, p.off_slots, p.Hkv, p.rot
     if (f16) {
-        hipLaunchKernelGGL((decode_mfma_kernel<D, G, 2, false, true>), grid, block, lds, st, p, slots_cap);
+        hipLaunchKernelGGL((decode_mfma_kernel<D, G, 2, false, true>), grid, block, lds, st, M355_HOT, p, slots_cap);
         return M355_OK;
     }
 #ifdef M355_DEV
 #define M355_RING(RR) if (R == RR) { \
-        if (stamp) hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, true>), grid, block, lds, st, p, slots_cap); \
-        else hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, false>), grid, block, lds, st, p, slots_cap); }
+        if (stamp) hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, true>), grid, block, lds, st, M355_HOT, p, slots_cap); \
+        else hipLaunchKernelGGL((decode_mfma_kernel<D, G, RR, false>), grid, block, lds, st, M355_HOT, p, slots_cap); }
     M355_RING(2) M355_RING(3) M355_RING(4) M355_RING(5) M355_RING(6)
 #undef M355_RING
 #else
     (void)stamp;
-    hipLaunchKernelGGL((decode_mfma_kernel<D, G, 2, false>), grid, block, lds, st, p, slots_cap);
+    hipLaunchKernelGGL((decode_mfma_kernel<D, G, 2, false>), grid, block, lds, st, M355_HOT, p, slots_cap);
 #endif
     return M355_OK;
 }
+
+#undef M355_HOT
 
 int launch_stream_mfma(const StreamParams& p, int D, int G, int64_t cap, hipStream_t st, bool stamp, bool f16) {
 #define M355_CASE(DD, GG) if (D == DD && G == GG) return launch_mfma<DD, GG>(p, cap, st, stamp, f16);

@@ -238,13 +238,20 @@ __device__ __forceinline__ void shstamp(const ShareParams& p, int wave, int k) {
             p.stamps[((size_t)blockIdx.x * (kShareMaxWaves + 1) + wave) * 8 + k] = __builtin_amdgcn_s_memrealtime();
 }
 
+// The leading scalar arguments repeat six fields of `p`: what a wave needs to ask for its first stage records.  Scalars in
+// front of the argument block are PRELOADED into SGPRs at wave launch (Makefile: -amdgpu-kernarg-preload-count), so the
+// record requests go out without first waiting for a load of the arguments themselves; `p` (a by-reference block that is
+// not preloaded) arrives meanwhile.
 template <int D, int G, bool F16, bool STAMP = false>
-__global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_kernel(const ShareParams p) {
+__global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_kernel(const int32_t* plan_hot, const int64_t off_rec_hot,
+                                                                                    const int32_t qcap_hot, const int32_t W_hot,
+                                                                                    const int32_t Hkv_hot, const int32_t rot_hot,
+                                                                                    const ShareParams p) {
     using M = MG<D>;
     using S = SG<D, G>;
     static_assert(G <= 16 && G * D >= 64, "group shape");
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
-    const int W = p.W;
+    const int W = W_hot;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     float* const parts = reinterpret_cast<float*>(smem + W * S::WAVEB);
@@ -254,20 +261,20 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
     shstamp<STAMP>(p, wave, 0);
     if (threadIdx.x < 8) ctl[threadIdx.x] = 0;           // (the one workgroup barrier that publishes this comes below, behind each
                                                          // wave's first loads)
-    const int share = blockIdx.x / p.Hkv;
+    const int share = blockIdx.x / Hkv_hot;
     // heads rotate over the XCDs (workgroups are dealt round-robin to them): see decode_mfma.hip
-    const int h = (blockIdx.x + (p.rot > 0 ? share / p.rot : 0)) % p.Hkv;
+    const int h = (blockIdx.x + (rot_hot > 0 ? share / rot_hot : 0)) % Hkv_hot;
     // a streaming wave's first two stage records sit at places known from the kernel arguments alone: asked for at once,
     // they travel beside the header loads below instead of behind them
-    const int32_t* const grec = p.plan + p.off_rec + ((int64_t)share * p.qcap + (wave < W ? wave : 0)) * kRecW;
+    const int32_t* const grec = plan_hot + off_rec_hot + ((int64_t)share * qcap_hot + (wave < W ? wave : 0)) * kRecW;
     const uint32_t rec0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem) + (wave < W ? wave : 0) * S::WAVEB + 2 * M::STAGEB;
     if (wave < W && lane < kRecW) {
         glds4(grec + lane, rec0);
         glds4(grec + (int64_t)W * kRecW + lane, rec0 + S::RECBYTES);
     }
-    const int Q = __builtin_amdgcn_readfirstlane(p.plan[kHShareStages]);
-    const int TS = __builtin_amdgcn_readfirstlane(p.plan[kHStages]);
-    const int rem = __builtin_amdgcn_readfirstlane(p.plan[kHShareRem]);
+    const int Q = __builtin_amdgcn_readfirstlane(plan_hot[kHShareStages]);
+    const int TS = __builtin_amdgcn_readfirstlane(plan_hot[kHStages]);
+    const int rem = __builtin_amdgcn_readfirstlane(plan_hot[kHShareRem]);
     const int SO = share_start(share, Q, rem);                       // the share = stages [SO, SO + NS) of the stream
     const int NS = TS - SO < Q + (share < rem) ? TS - SO : Q + (share < rem);
     if (NS <= 0) { wait_vmcnt<0>(); return; }                        // (no LDS-DMA may outlive its wave)
@@ -737,7 +744,8 @@ static int launch_share(const ShareParams& p, int lds, hipStream_t st) {
         }
         allowed.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((decode_share_kernel<D, G, F16>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), lds, st, p);
+    hipLaunchKernelGGL((decode_share_kernel<D, G, F16>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), lds, st,
+                       (const int32_t*)p.plan, p.off_rec, p.qcap, p.W, p.Hkv, p.rot, p);
     return M355_OK;
 }
 
@@ -751,7 +759,8 @@ int launch_share_attn(ShareParams& p, int D, int G, bool f16, hipStream_t st, bo
 #define M355_STAMPED(DD, GG) if (D == DD && G == GG) { \
             static bool allowed = false; \
             if (!allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_share_kernel<DD, GG, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); allowed = true; } \
-            hipLaunchKernelGGL((decode_share_kernel<DD, GG, false, true>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), sh.lds_bytes, st, p); \
+            hipLaunchKernelGGL((decode_share_kernel<DD, GG, false, true>), dim3((unsigned)(p.nb * p.Hkv)), dim3(64 * (p.W + 1)), sh.lds_bytes, st, \
+                               (const int32_t*)p.plan, p.off_rec, p.qcap, p.W, p.Hkv, p.rot, p); \
             return M355_OK; }
         M355_STAMPED(64, 4) M355_STAMPED(128, 4) M355_STAMPED(128, 8)
 #undef M355_STAMPED

@@ -121,7 +121,9 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t* __restri
         run += pieces_of(cu[b], cu[b + 1], R);
     }
     if (tid == 1023) { pbase[B] = run; if (staged) pb_s[B] = run; }
+#ifdef M355_DEV      // (the arrival counts belong to the dev build's in-kernel merge; the product never looks at them)
     for (int64_t k = tid; k < ((int64_t)L.max_ranges + B) * Hkv; k += 1024) plan[L.arrivals + k] = 0;
+#endif
     __syncthreads();
     const int32_t* pb = staged ? pb_s : pbase;
     // range records
@@ -442,12 +444,14 @@ __global__ __launch_bounds__(64, W) void decode_stream_kernel(const StreamParams
 #endif  // M355_DEV
 
 template <int D, int NW, bool F16 = false>
-__global__ __launch_bounds__(64 * NW) void stream_merge_kernel(const StreamParams p) {
-    const int b = blockIdx.x / p.Hq;
-    const int hq = blockIdx.x % p.Hq;
-    const int32_t* pbase = p.plan + p.off_pbase;
-    const int32_t* cum = p.plan + p.off_cum;
-    const int32_t R = p.plan[1];
+__global__ __launch_bounds__(64 * NW) void stream_merge_kernel(const int32_t* plan_hot, const int64_t off_pbase_hot, const int64_t off_cum_hot,
+                                                               const int32_t Hq_hot, const StreamParams p) {
+    // (leading scalars: preloaded into SGPRs at wave launch, see decode_mfma.hip - the first loads leave at once)
+    const int b = blockIdx.x / Hq_hot;
+    const int hq = blockIdx.x % Hq_hot;
+    const int32_t* pbase = plan_hot + off_pbase_hot;
+    const int32_t* cum = plan_hot + off_cum_hot;
+    const int32_t R = plan_hot[1];
     const int32_t cs = cum[b], ce = cum[b + 1];
     const int np = pieces_of(cs, ce, R);
     if (np <= 1) return;                                  // whole request handled by one wave: output already final
@@ -653,9 +657,9 @@ template <int D, bool F16 = false>
 static void launch_merge(const StreamParams& p, hipStream_t st) {
     const int per_req = p.nwh / (p.B > 0 ? p.B : 1);
     const dim3 grid((unsigned)(p.B * p.Hq));
-    if (per_req >= 64) hipLaunchKernelGGL((stream_merge_kernel<D, 16, F16>), grid, dim3(1024), 0, st, p);
-    else if (per_req >= 16) hipLaunchKernelGGL((stream_merge_kernel<D, 4, F16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((stream_merge_kernel<D, 1, F16>), grid, dim3(64), 0, st, p);
+    if (per_req >= 64) hipLaunchKernelGGL((stream_merge_kernel<D, 16, F16>), grid, dim3(1024), 0, st, p.plan, p.off_pbase, p.off_cum, p.Hq, p);
+    else if (per_req >= 16) hipLaunchKernelGGL((stream_merge_kernel<D, 4, F16>), grid, dim3(256), 0, st, p.plan, p.off_pbase, p.off_cum, p.Hq, p);
+    else hipLaunchKernelGGL((stream_merge_kernel<D, 1, F16>), grid, dim3(64), 0, st, p.plan, p.off_pbase, p.off_cum, p.Hq, p);
 }
 
 #ifdef M355_DEV
