@@ -124,14 +124,25 @@ __global__ __launch_bounds__(1024) void share_plan_kernel(const int64_t* __restr
     if (tid < nb) {
         int32_t* e = plan + L.share + (int64_t)tid * kShareW;
         const int64_t s0 = share_start(tid, Q, rem);
-        int32_t bf = 0, bl = -1;
+        int32_t bf = 0, bl = -1, early = 0;
         if (s0 < TS) {
             const int32_t s1 = (int32_t)min((int64_t)TS, s0 + Q + (tid < rem));
             bf = ub_minus1(sg, B, (int32_t)s0);
             bl = ub_minus1(sg, B, s1 - 1);
+            // A share's segments are walked last request first, so the tail of a request that began in an earlier share (it
+            // waits for that share's hand-off) comes last.  When that tail is SHORT it ends in the same round of stages as the
+            // segment before it and the finishing wave serves the two one after the other - 0.8 us more behind the last stage,
+            // on exactly the workgroups that end the launch.  Such a tail is walked SECOND instead (behind the segment that is
+            // published): it is done early, its partial waits in the finishing wave's registers for the hand-off.
+            // (Also tried: tails of up to 16 stages, and walking the whole requests in between in the direction that ends with
+            // the longer one - no further gain on configs[1] or the 8B shape.)
+            const int32_t* nzp = staged ? nz_s : nz;
+            if (bl > bf && bl - bf < 63 && sg[bf] < (int32_t)s0 && min(sg[bf + 1], s1) - (int32_t)s0 <= kShareEarlyStages &&
+                nzp[bl] - nzp[bf] >= 2)
+                early = 1;
         }
-        e[0] = bf; e[1] = bl;
-        for (int k = 2; k < kShareW; ++k) e[k] = 0;
+        e[0] = bf; e[1] = bl; e[2] = early;
+        for (int k = 3; k < kShareW; ++k) e[k] = 0;
     }
     if (tid == 0) {
         plan[kHTotal] = cu[B]; plan[kHShareStages] = Q; plan[kHB] = B; plan[kHShares] = nb; plan[kHWaves] = W;
@@ -164,13 +175,19 @@ __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restri
         const int32_t s0 = share_start(i, Q, rem), s1 = min(TS, s0 + Q + (i < rem));
         const int32_t a = max(sb0, s0), e = min(sb1, s1);                     // the segment = this request's stages in the share
         const int32_t st = v - a, seg_n = e - a;
-        const int32_t sl = (s1 - e) + st;                                     // the share's segments are walked last to first
+        const int32_t* she = plan + L.share + (int64_t)i * kShareW;
+        const int32_t bf_i = she[0], bl = she[1];
+        int32_t sl = (s1 - e) + st;                                           // the share's segments are walked last to first
+        int32_t ord = nz[bl] - nz[b];
+        if (she[2]) {                                                         // ... except a short first one, which is walked second
+            if (b == bf_i) { sl = (s1 - max(stg[bl], s0)) + st; ord = 1; }
+            else if (b != bl) { sl += min(stg[bf_i + 1], s1) - s0; ord += 1; }
+        }
         int32_t* rec = plan + L.rec + ((int64_t)i * L.qcap + sl) * kRecW;
         const int32_t pg = tok / ps;
         const int32_t slot = page_table[rows[b] * pt_stride + pg] * ps + (tok - pg * ps);
         rec[idx] = slot;
         if (idx == 0) {
-            const int32_t bl = plan[L.share + (int64_t)i * kShareW + 1];
             int32_t meta = min(kStageTok, len - (tok / kStageTok) * kStageTok);
             if (st < W) meta |= kRecFirst;                              // the owning wave's previous stage lies before the segment
             if (st + W >= seg_n) meta |= kRecLast;                      // ... its next one behind it
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(256) void share_fill_kernel(const int32_t* __restri
             if (v == sb1 - 1 && (int64_t)len == seq_lens[b]) meta |= kRecNewest;
             rec[kRecB] = b;
             rec[kRecMeta] = meta;
-            rec[kRecOrd] = nz[bl] - nz[b];
+            rec[kRecOrd] = ord;
             for (int k = kRecOrd + 1; k < kRecW; ++k) rec[k] = 0;
         }
         if (tok == len - 1)                                             // pad the request's last stage with its last slot
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
         const int32_t* sh = p.plan + p.off_share + (int64_t)share * kShareW;
         const int bf = __builtin_amdgcn_readfirstlane(sh[0]);
         const int bl = __builtin_amdgcn_readfirstlane(sh[1]);
+        const int early = __builtin_amdgcn_readfirstlane(sh[2]);    // the share's first request (a short tail) is walked second
         const int32_t* stg = p.plan + p.off_stg;
         const int S1 = SO + NS;
         constexpr int VEC = S::VEC;
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
         u32x4* const gran = reinterpret_cast<u32x4*>(p.plan + p.off_gran) + (int64_t)h * p.nb * (NG * 64);
         const int e0 = lane * VEC;                                   // first of this lane's elements of O[G][D]
         const int g = e0 / D, d0 = e0 - g * D;
-        // hand-off state: only the share's LAST segment can end a request that began in an earlier share
+        // hand-off state: only the share's FIRST request can end a request that began in an earlier share
         int cross_left = 0, cross_next = share - 1;
         {
             const int f0 = __builtin_amdgcn_readfirstlane(stg[bf]);
@@ -319,6 +337,38 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
 #pragma unroll
         for (int k = 0; k < NG; ++k) *reinterpret_cast<u32x4*>(stage + k * 1024 + 16 * lane) = u32x4{0u, 0u, 0u, 0u};
         int cage = kCrossEvery;
+        auto store_out = [&](const int b, const float den, const float (&acc)[VEC]) {
+            const float inv = __builtin_amdgcn_rcpf(den);            // (one instruction, 1 ulp; the division is a dozen)
+            uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)(h * G + g) * D + d0;
+            if constexpr (VEC == 1) {
+                *op = (uint16_t)(pack16<F16>(acc[0] * inv, 0.f) & 0xffffu);
+            } else {
+                uint32_t wds[VEC / 2];
+#pragma unroll
+                for (int x = 0; x < VEC / 2; ++x) wds[x] = pack16<F16>(acc[2 * x] * inv, acc[2 * x + 1] * inv);
+                if constexpr (VEC == 2) *reinterpret_cast<uint32_t*>(op) = wds[0];
+                else if constexpr (VEC == 4) *reinterpret_cast<uint2*>(op) = make_uint2(wds[0], wds[1]);
+                else {
+#pragma unroll
+                    for (int x = 0; x < VEC / 8; ++x)
+                        *reinterpret_cast<u32x4*>(op + 8 * x) = u32x4{wds[4 * x], wds[4 * x + 1], wds[4 * x + 2], wds[4 * x + 3]};
+                }
+            }
+        };
+        // a merge segment that was walked early and found the hand-off still open: its own (m, l, O) wait here
+        bool pend_m = false;
+        int pend_b = 0;
+        float pend_gm = 0.f, pend_den = 0.f, pend_acc[VEC];
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) pend_acc[x] = 0.f;
+        auto finish_merge = [&](const int b, const float gm, float den, float (&acc)[VEC]) {   // hand-off (cm, cl, cacc) + own part -> output
+            const float nm = fmaxf(cm, gm);
+            const float wa = exp2_fast(cm - nm), wb = exp2_fast(gm - nm);
+            den = cl * wa + den * wb;
+#pragma unroll
+            for (int x = 0; x < VEC; ++x) acc[x] = cacc[x] * wa + acc[x] * wb;
+            store_out(b, den, acc);
+        };
         auto cross_step = [&]() {
             const u32x4* src = gran + (int64_t)cross_next * (NG * 64) + lane;
             if (++cage >= kCrossEvery) {                             // ask (again): served past this CU's L1 (sc1)
@@ -354,19 +404,34 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             for (int k = 0; k < NG; ++k) st_agent16(const_cast<u32x4*>(src) + k * 64, u32x4{0u, 0u, 0u, 0u});
             --cross_next; --cross_left;
             cage = kCrossEvery;                                      // the next publisher's granules are asked for at once
-            if (cross_left == 0) shstamp<STAMP>(p, wave, 3);
+            if (cross_left == 0) {
+                shstamp<STAMP>(p, wave, 3);
+                if (pend_m) { finish_merge(pend_b, pend_gm, pend_den, pend_acc); pend_m = false; }
+            }
         };
         // the segments, last request first; their stage ranges come from stg, 64 requests per load
         int base = 0, ord = 0;
         int wb = bl + 1;                                             // lanes hold requests wb-1, wb-2, ... of the current window
         int32_t w0 = 0, w1 = 0;
-        for (int b = bl; b >= bf; --b) {
-            if (b < wb - 63 || b == bl) {
-                wb = b + 1;
-                const int bb = b - lane;
-                w0 = bb >= bf ? stg[bb] : 0;
-                w1 = bb >= bf ? stg[bb + 1] : 0;
-            }
+        // The window is loaded OUTSIDE the segment loop (and again, rarely, after 64 segments), and the loaded values are made
+        // to be "used" right there: hipcc then waits for the loads there.  With the first load inside the loop it waited at the
+        // top of EVERY iteration - s_waitcnt vmcnt(0), which also waits for the previous segment's output store (~0.8 us) and
+        // for whatever hand-off DMA is in flight (2-3.5 us on a streaming chip): two segments that complete together were
+        // served 0.8 us apart (the workgroups that ended a launch: shares whose last segment is a stage or two), and a
+        // segment that arrived behind a hand-off request waited for the request.
+        auto load_window = [&](const int b) {
+            wb = b + 1;
+            const int bb = b - lane;
+            w0 = bb >= bf ? stg[bb] : 0;
+            w1 = bb >= bf ? stg[bb + 1] : 0;
+            asm volatile("" : "+v"(w0), "+v"(w1));
+        };
+        load_window(bl);
+        const int nreq = bl - bf + 1;
+        for (int k = 0; k < nreq; ++k) {
+            // walk order: bl, bl-1, ..., bf - or, with a short first request, bl, bf, bl-1, ..., bf+1 (all inside one window then)
+            const int b = early ? (k == 0 ? bl : (k == 1 ? bf : bl - (k - 1))) : bl - k;
+            if (b < wb - 63) load_window(b);
             const int sb0 = __shfl(w0, wb - 1 - b), sb1 = __shfl(w1, wb - 1 - b);
             if (sb1 == sb0) continue;                                // empty request
             const int lo_ = sb0 > SO ? sb0 : SO, hi_ = sb1 < S1 ? sb1 : S1;
@@ -384,7 +449,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
             }
             asm volatile("" ::: "memory");
             if (ord == 0) shstamp<STAMP>(p, wave, 2);
-            if (b == bf) shstamp<STAMP>(p, wave, 4);
+            if (k == nreq - 1) shstamp<STAMP>(p, wave, 4);
             // All partials of the segment are requested at once, as whole vectors and from addresses that hold a partial for
             // EVERY w (a wave that took no part stands in wave `first`'s and gets weight 0): no branches, ONE LDS latency.
             // (Selecting the loaded values instead made hipcc branch around each load and wait for each wave's reads in
@@ -419,7 +484,7 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                 for (int x = 0; x < VEC; ++x) acc[x] = fmaf(wgt, pa[w][x], acc[x]);
             }
 #ifdef M355_TAIL_STAMPS
-            if (b == bf) shstamp<STAMP>(p, wave, 6);
+            if (k == nreq - 1) shstamp<STAMP>(p, wave, 6);
 #endif
             if (lane == 0) {                                         // slot free: count back to zero first, then release
                 __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -443,40 +508,35 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                 continue;
             }
             if (kind == kSegMerge) {
-                int spins2 = 0;
-                while (cross_left > 0 && !failed) {                 // whatever of the hand-off is still open: now it is waited for
-                    cross_step();
-                    if (cross_left > 0) __builtin_amdgcn_s_sleep(2);
-                    if (++spins2 > kPollLimit) failed = true;
-                }
-                const float nm = fmaxf(cm, gm);
-                const float wa = exp2_fast(cm - nm), wb = exp2_fast(gm - nm);
-                den = cl * wa + den * wb;
+                if (early && cross_left > 0) {                       // walked early, the hand-off is still on its way: finished when it is
+                    pend_m = true; pend_b = b; pend_gm = gm; pend_den = den;
 #pragma unroll
-                for (int x = 0; x < VEC; ++x) acc[x] = cacc[x] * wa + acc[x] * wb;
-            }
-            {
-                const float inv = __builtin_amdgcn_rcpf(den);        // (one instruction, 1 ulp; the division is a dozen)
-                uint16_t* op = p.out + (int64_t)b * p.o_stride + (int64_t)(h * G + g) * D + d0;
-                if constexpr (VEC == 1) {
-                    *op = (uint16_t)(pack16<F16>(acc[0] * inv, 0.f) & 0xffffu);
+                    for (int x = 0; x < VEC; ++x) pend_acc[x] = acc[x];
                 } else {
-                    uint32_t wds[VEC / 2];
-#pragma unroll
-                    for (int x = 0; x < VEC / 2; ++x) wds[x] = pack16<F16>(acc[2 * x] * inv, acc[2 * x + 1] * inv);
-                    if constexpr (VEC == 2) *reinterpret_cast<uint32_t*>(op) = wds[0];
-                    else if constexpr (VEC == 4) *reinterpret_cast<uint2*>(op) = make_uint2(wds[0], wds[1]);
-                    else {
-#pragma unroll
-                        for (int x = 0; x < VEC / 8; ++x)
-                            *reinterpret_cast<u32x4*>(op + 8 * x) = u32x4{wds[4 * x], wds[4 * x + 1], wds[4 * x + 2], wds[4 * x + 3]};
+                    int spins2 = 0;
+                    while (cross_left > 0 && !failed) {             // whatever of the hand-off is still open: now it is waited for
+                        cross_step();
+                        if (cross_left > 0) __builtin_amdgcn_s_sleep(2);
+                        if (++spins2 > kPollLimit) failed = true;
                     }
+                    finish_merge(b, gm, den, acc);
                 }
+            } else {
+                store_out(b, den, acc);
             }
 #ifdef M355_TAIL_STAMPS
-            if (b == bf) shstamp<STAMP>(p, wave, 7);
+            if (k == nreq - 1) shstamp<STAMP>(p, wave, 7);
 #endif
             ++ord;
+        }
+        if (pend_m) {                                                // every segment is served; the hand-off is all that is left
+            int spins2 = 0;
+            while (cross_left > 0 && !failed) {
+                cross_step();
+                if (cross_left > 0) __builtin_amdgcn_s_sleep(2);
+                if (++spins2 > kPollLimit) failed = true;
+            }
+            if (pend_m) finish_merge(pend_b, pend_gm, pend_den, pend_acc);   // (not yet done by the step that completed the hand-off)
         }
         if (failed && lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(p.plan) + kHError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wait_vmcnt<0>();                                             // (no LDS-DMA may outlive its wave; none is left unless the hand-off came late)

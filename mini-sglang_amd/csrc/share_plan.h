@@ -14,7 +14,8 @@ constexpr int kRecFirst = 1 << 8;               // meta flag: the owning wave's 
 constexpr int kRecLast = 1 << 9;                // meta flag: the owning wave's last stage of this segment
 constexpr int kRecNewest = 1 << 10;             // meta flag: token valid-1 of the stage is the request's newest token
 constexpr int kShareHdr = 16;                   // plan header words
-constexpr int kShareW = 8;                      // words per share entry: {first request, last request, ...}
+constexpr int kShareW = 8;                      // words per share entry: {first request, last request, first request walked second, ...}
+constexpr int kShareEarlyStages = 8;            // a first request of at most this many stages (one round of the 8 waves) is walked second
 constexpr int kSegWhole = 0, kSegPublish = 1, kSegMerge = 2;     // a segment = one request's stages inside one share
 constexpr int kShareMinStages = 4;              // shortest share
 constexpr int kShareMaxWaves = 8;               // streaming waves per workgroup (plus one finishing wave)
