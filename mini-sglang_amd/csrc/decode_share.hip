@@ -697,7 +697,9 @@ __global__ __launch_bounds__(64 * (share_max_waves(D) + 1)) void decode_share_ke
                 const bool isv = lane >= M::C;
                 const uint8_t* src = st + (isv ? M::TILEB : 0) + row * M::ROWB + 16 * (c ^ (isv ? M::sV(row) : M::sK(row)));
                 pend_data = *reinterpret_cast<const u32x4*>(src);
-                pend_dst = (isv ? p.v_pool : p.k_pool) + (int64_t)rc[row] * p.row_elems + h * D + c * 8;
+                // (from the bases already in registers: written as a choice between the two kernel ARGUMENTS, hipcc fetched the
+                // chosen pointer with a vector load and waited for it with vmcnt(0) - i.e. for the next stage's DMA as well)
+                pend_dst = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(isv ? vbase : kbase) + (int64_t)rc[row] * row_bytes) + c * 8;
             }
             pend = true;
         }
