@@ -4,6 +4,7 @@ Everything here is device set-up plus HIP-event timing around calls into mi355_a
 """
 from __future__ import annotations
 
+import os
 import random
 from types import SimpleNamespace
 from typing import List, Optional, Sequence
@@ -136,6 +137,11 @@ def prefill_cfg3_case(dev: str, Hq: int = 32, Hkv: int = 8, D: int = 128, ps: in
     random.seed(0)
     B = groups * per_group
     ext = [random.randint(*suffix) for _ in range(B)]
+    grp = [i // per_group for i in range(B)]
+    exp_order = os.environ.get("M355_EXP_REQ_ORDER", "")          # experiment: batch order by new-token count (the groups' sharing is kept)
+    if exp_order:
+        idx = sorted(range(B), key=lambda i: ext[i], reverse=exp_order == "desc")
+        ext, grp = [ext[i] for i in idx], [grp[i] for i in idx]
     pre = [prefix // ps * ps] * B
     seq = [p + e for p, e in zip(pre, ext)]
     T = sum(ext)
@@ -144,12 +150,10 @@ def prefill_cfg3_case(dev: str, Hq: int = 32, Hkv: int = 8, D: int = 128, ps: in
     it = iter(torch.randperm(pages_total, generator=torch.Generator().manual_seed(0)).tolist())
     W = max(-(-s // ps) for s in seq) + 1
     table = torch.zeros((B, W), dtype=torch.int32)
-    for gi in range(groups):
-        shared = [next(it) for _ in range(npp)]
-        for k in range(per_group):
-            b = gi * per_group + k
-            own = [next(it) for _ in range(-(-seq[b] // ps) - npp)]
-            table[b, : npp + len(own)] = torch.tensor(shared + own, dtype=torch.int32)
+    shared = [[next(it) for _ in range(npp)] for _ in range(groups)]
+    for b in range(B):
+        own = [next(it) for _ in range(-(-seq[b] // ps) - npp)]
+        table[b, : npp + len(own)] = torch.tensor(shared[grp[b]] + own, dtype=torch.int32)
     g = torch.Generator(device=dev).manual_seed(0)
     pools = [(torch.randn((pages_total * ps, Hkv, D), generator=g, device=dev).to(torch.bfloat16),
               torch.randn((pages_total * ps, Hkv, D), generator=g, device=dev).to(torch.bfloat16)) for _ in range(layers)]

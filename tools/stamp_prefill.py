@@ -35,7 +35,7 @@ rows = torch.arange(B, device=dev)
 out = torch.empty_like(q)
 tiles_max = (E * (Hq // Hkv) + 32 * NW - 1) // (32 * NW)
 nblocks = B * Hkv * tiles_max
-stamps = torch.zeros((nblocks * NW, 8), dtype=torch.int64, device=dev)
+stamps = torch.zeros((nblocks * NW, 16), dtype=torch.int64, device=dev)
 lib = _lib.load()
 lib.m355dbg_set_prefill_stamp_buffer.argtypes = [ctypes.c_void_p]
 
