@@ -19,8 +19,6 @@
 // K/V of the new tokens are read back from the pool (the KV write precedes this kernel on the stream).
 #include <stdlib.h>
 
-#include <atomic>
-
 #include "prefill_common.h"
 
 namespace m355 {
@@ -227,13 +225,7 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillParams p
 // ds_read_b64_tr_b16 transposed reads.  L2->CU traffic drops by 4 against one-wave-per-tile streaming, which was
 // what bounded the first kernel (3.3 GB per layer on the 8B shared-prefix workload).
 // ------------------------------------------------------------------------------------------------
-// Work counters of the persistent form: per launch a group of 16 words, [x] = next item of virtual XCD x, [8 + x] = its
-// workgroups that have left.  The last workgroup to leave zeroes its XCD's pair, so a group is zero whenever no launch is
-// using it; the host hands groups out round-robin (kCtrSlots launches would have to overlap on one GPU to share one).
-__device__ int32_t g_prefill_ctr[kCtrSlots * kCtrWords];
-constexpr int kAuxAgent = 16;                         // cache policy operand of the buffer builtins on gfx950: sc1 (agent scope)
-
-template <int D, int G, int NW, int NBUF, bool POW2, bool STAMP = false, bool F16 = false, bool PERSIST = false>
+template <int D, int G, int NW, int NBUF, bool POW2, bool STAMP = false, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(const PrefillParams p) {
     using W = WgCfg<D>;
     constexpr int NT = 64 * NW;                       // threads
@@ -257,90 +249,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     if constexpr (STAMP) r_entry = __builtin_amdgcn_s_memrealtime();
     const int n_bh = p.B * p.Hkv;
     const int mapped = (n_bh >> 3) * 8 * p.tiles_max;              // workgroups of the full rounds
-    // ---- persistent form: as many workgroups as the chip holds; each takes the next live row block of its XCD from a
-    // counter (the order is the dispatch order of the one-block-per-workgroup form, minus the blocks that do not exist)
-    // instead of ending and being replaced - 3-4 us of empty slot per block.  Segment s of XCD x = one (request, kv head):
-    // s < n_full: pair 8 s + x, all its blocks, latest first; then the pairs left over after the last full round of 8,
-    // every eighth block each.  segcum[s] = blocks before segment s.
-    int32_t* const segcum = slotw + kSlotWin;
-    int32_t* const bcast = segcum + kMaxSeg + 1;
-    const int vx = blockIdx.x & 7;
-    const int n_full = n_bh >> 3, n_seg = n_full + (n_bh & 7);
-    int32_t* const ctr = g_prefill_ctr + p.ctr_slot * kCtrWords;
-    int item = 0, total = 0;
-    if constexpr (PERSIST) {
-        int32_t first = 0;
-        if (threadIdx.x == 0) first = __hip_atomic_fetch_add(ctr + vx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int s = threadIdx.x; s < n_seg; s += NT) {
-            const int bq = (s < n_full ? 8 * s + vx : (n_bh & ~7) + (s - n_full)) / p.Hkv;
-            const int nt = ((int)(p.seq_lens[bq] - p.prefix_lens[bq]) * G + ROWS_WG - 1) / ROWS_WG;
-            segcum[s + 1] = s < n_full ? nt : (nt > vx ? (nt - vx + 7) >> 3 : 0);
-        }
-        if (threadIdx.x == 0) { segcum[0] = 0; bcast[0] = first; }
-        __syncthreads();
-        if (wid == 0) {                                            // inclusive scan, a run of segments per lane
-            const int per = (n_seg + 63) >> 6, base = l * per;
-            int sum = 0;
-            for (int k = 0; k < per; ++k) sum += base + k < n_seg ? segcum[base + k + 1] : 0;
-            int inc = sum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); inc += l >= d ? t : 0; }
-            int run = inc - sum;
-            for (int k = 0; k < per; ++k)
-                if (base + k < n_seg) { run += segcum[base + k + 1]; segcum[base + k + 1] = run; }
-        }
-        __syncthreads();
-        total = segcum[n_seg];
-        item = bcast[0];
-    }
-    // The last, partly filled round of an XCD: its row blocks (at most kTailBlocks of them) are cut along KV into 2 or 4
-    // pieces that are work items of their own, so that the chip's last round is full and half or a quarter as long; a
-    // piece leaves its (O, m, l) in the exchange area in register layout and counts itself in, the last one to arrive
-    // adds the others' to its registers and writes the block's output.
-    int nwhole = total, tails = 1;
-    if constexpr (PERSIST) {
-        const int nslot = ((int)gridDim.x - vx + 7) >> 3;
-        if (p.tail_ws != nullptr && total > nslot && total % nslot) {
-            const int tailn = total % nslot < kTailBlocks ? total % nslot : kTailBlocks;
-            tails = tailn > kTailPieces / 4 ? 2 : 4;
-            nwhole = total - tailn;
-        }
-    }
-    const int n_items = nwhole + (total - nwhole) * tails;
-    for (;;) {
     int tb, bh;
-    int32_t next_item = 0;
-    int sp_i = 0, sp_n = 1, tq = 0;                                // KV piece of this item, pieces of its block, piece number in the XCD's tail
-    if constexpr (STAMP && PERSIST) r_entry = __builtin_amdgcn_s_memrealtime();
-    if constexpr (PERSIST) {
-        if (item >= n_items) break;
-        int blk = item;
-        if (item >= nwhole) { tq = item - nwhole; blk = nwhole + tq / tails; sp_i = tq % tails; sp_n = tails; }
-        int lo = 0, hi = n_seg - 1;                                // segment holding block `blk` (workgroup-uniform)
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segcum[mid] <= blk) lo = mid; else hi = mid - 1; }
-        const int j = blk - segcum[lo];
-        if (lo < n_full) { bh = 8 * lo + vx; tb = segcum[lo + 1] - segcum[lo] - 1 - j; }
-        else {
-            bh = (n_bh & ~7) + (lo - n_full);
-            const int bq = bh / p.Hkv;
-            tb = ((int)(p.seq_lens[bq] - p.prefix_lens[bq]) * G + ROWS_WG - 1) / ROWS_WG - 1 - vx - 8 * j;
-        }
-        bh = __builtin_amdgcn_readfirstlane(bh); tb = __builtin_amdgcn_readfirstlane(tb);
-    } else if ((int)blockIdx.x < mapped) {
-        int item1 = blockIdx.x >> 3;
-        tb = p.tiles_max - 1 - item1 % p.tiles_max;
-        bh = (item1 / p.tiles_max) * 8 + (blockIdx.x & 7);
+    if ((int)blockIdx.x < mapped) {
+        int item = blockIdx.x >> 3;
+        tb = p.tiles_max - 1 - item % p.tiles_max;
+        bh = (item / p.tiles_max) * 8 + (blockIdx.x & 7);
     } else {
-        const int item1 = blockIdx.x - mapped;
-        tb = p.tiles_max - 1 - item1 % p.tiles_max;
-        bh = (n_bh & ~7) + item1 / p.tiles_max;
+        const int item = blockIdx.x - mapped;
+        tb = p.tiles_max - 1 - item % p.tiles_max;
+        bh = (n_bh & ~7) + item / p.tiles_max;
     }
     const int h = bh % p.Hkv;
     const int b = bh / p.Hkv;
     const int P = (int)p.prefix_lens[b];
     const int E = (int)p.seq_lens[b] - P;
     const int rows_b = E * G;
-    if (ROWS_WG * tb >= rows_b) return;                            // whole workgroup: no barrier has been reached yet (persistent form: never)
+    if (ROWS_WG * tb >= rows_b) return;                            // whole workgroup: no barrier has been reached yet
     const int32_t* pt_row = p.page_table + p.page_table_ids[b] * p.pt_stride;
     const int64_t qrow0 = p.cu_q[b];
     const int j_last_wg = min(E - 1, (ROWS_WG * tb + ROWS_WG - 1) / G);
@@ -348,9 +272,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     const int n_tiles = (kv_end_wg + 31) >> 5;
     const int n_pairs_all = (n_tiles + 1) >> 1;
     // split-KV (few row blocks, long KV): this workgroup walks pairs [p_begin, n_pairs) only and leaves fp32 partials
-    const int sp_cnt = PERSIST ? sp_n : p.splits, sp_idx = PERSIST ? sp_i : (int)blockIdx.y;
-    const int p_begin = sp_cnt > 1 ? (int)((int64_t)n_pairs_all * sp_idx / sp_cnt) : 0;
-    const int n_pairs = sp_cnt > 1 ? (int)((int64_t)n_pairs_all * (sp_idx + 1) / sp_cnt) : n_pairs_all;   // exclusive end
+    const int p_begin = p.splits > 1 ? (int)((int64_t)n_pairs_all * blockIdx.y / p.splits) : 0;
+    const int n_pairs = p.splits > 1 ? (int)((int64_t)n_pairs_all * (blockIdx.y + 1) / p.splits) : n_pairs_all;   // exclusive end
 
     // ---- this wave's row tile: the lane's row, its limit, Q^T fragments
     const int t = tb * NW + wid;                                   // row tile index inside the request
@@ -543,15 +466,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         wait_vmcnt<(NP - 2) * 2 * IPW>();                          // pair k has landed; NP-2 younger pairs stay in flight
         __syncthreads();
         stamp(0);
-        if constexpr (PERSIST) {
-            // The next block's number is asked for two pair steps before the end (not at the start: a workgroup in a long
-            // block would sit on a block that free workgroups then start after later ones) and parked in LDS one step on.
-            const int kf = n_pairs - 2 > p_begin ? n_pairs - 2 : p_begin;
-            if (threadIdx.x == 0) {
-                if (k == kf) next_item = __hip_atomic_fetch_add(ctr + vx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (k == kf + 1 || n_pairs - p_begin == 1) bcast[0] = next_item;
-            }
-        }
         // the pair NP-1 ahead goes into the buffers that pair k-1 vacated (slots now, DMA further down)
         constexpr int nb = 2 * ((pb + NP - 1) % NP);
         int32_t sl[IPW];
@@ -628,68 +542,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     wait_vmcnt<0>();                                               // the clamped re-fetches of the last pairs must not outlive the wave
     if constexpr (STAMP) {
         if (l == 0 && p.stamps) {
-            unsigned long long* d = p.stamps + ((int64_t)(PERSIST ? bh * p.tiles_max + tb : (int)blockIdx.x) * NW + wid) * 16;
+            unsigned long long* d = p.stamps + ((int64_t)blockIdx.x * NW + wid) * 16;
             for (int i = 0; i < 5; ++i) d[i] = tacc[i];
             d[8] = r_entry; d[9] = rfirst; d[10] = __builtin_amdgcn_s_memrealtime();   // absolute: kernel entry, first pair, loop end
-            d[11] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; d[12] = (unsigned long long)(bh * 65536 + tb);
+            d[11] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;                      // XCC_ID
             d[5] = __builtin_amdgcn_s_memrealtime() - rfirst;      // 100 MHz ticks (the 'between pairs' sum is folded into phase 4)
             d[6] = __builtin_amdgcn_s_memtime() - tfirst;
             d[7] = (unsigned long long)n_pairs;
-        }
-    }
-    bool write_out = true;
-    if constexpr (PERSIST) {
-        if (n_pairs <= p_begin && threadIdx.x == 0)                // (a piece without pairs never reached the look-ahead above)
-            bcast[0] = __hip_atomic_fetch_add(ctr + vx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (sp_n > 1) {
-            // piece tq of this XCD: chunk x (16 bytes per lane; DT*4 of O^T, then {m, l}) sits at ((piece * NCH + x) * NT + thread) * 16
-            constexpr int NCH = W::DT * 4 + 1;
-            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.tail_ws, 0, 0x7fffffff, 0x00020000);
-            const uint32_t mine = ((uint32_t)(vx * kTailPieces + tq) * NCH * NT + threadIdx.x) * 16;
-#pragma unroll
-            for (int dt = 0; dt < W::DT; ++dt)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        u32x4{__builtin_bit_cast(uint32_t, o[dt][4 * q4 + 0]), __builtin_bit_cast(uint32_t, o[dt][4 * q4 + 1]),
-                              __builtin_bit_cast(uint32_t, o[dt][4 * q4 + 2]), __builtin_bit_cast(uint32_t, o[dt][4 * q4 + 3])},
-                        xr, mine + (uint32_t)(dt * 4 + q4) * NT * 16, 0, kAuxAgent);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(uint32_t, m_run), __builtin_bit_cast(uint32_t, l_run), 0u, 0u},
-                                                   xr, mine + (uint32_t)(W::DT * 4) * NT * 16, 0, kAuxAgent);
-            wait_vmcnt<0>();                                       // written through (sc1) and acknowledged
-            __syncthreads();                                       // ... by every wave of the workgroup
-            int32_t* const arrived = ctr + 16 + vx * kTailBlocks + tq / sp_n;
-            if (threadIdx.x == 0) {
-                const int old = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == sp_n - 1) __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                bcast[1] = old;
-            }
-            __syncthreads();
-            write_out = bcast[1] == sp_n - 1;                       // the last piece to arrive finishes the block
-            if (write_out) {
-                for (int j = 0; j < sp_n; ++j) {
-                    if (j == sp_i) continue;
-                    const uint32_t theirs = ((uint32_t)(vx * kTailPieces + tq - sp_i + j) * NCH * NT + threadIdx.x) * 16;
-                    const u32x4 ml = __builtin_amdgcn_raw_buffer_load_b128(xr, theirs + (uint32_t)(W::DT * 4) * NT * 16, 0, kAuxAgent);
-                    const uint32_t ml0 = ml[0], ml1 = ml[1];      // (hipcc 7.2: a bit_cast of a vector ELEMENT reads element 0)
-                    const float m2 = __builtin_bit_cast(float, ml0), l2 = __builtin_bit_cast(float, ml1);
-                    const float mn = fmaxf(m_run, m2);
-                    const float a1 = exp2_fast(m_run - mn), a2 = exp2_fast(m2 - mn);
-                    m_run = mn;
-                    l_run = fmaf(l_run, a1, l2 * a2);
-#pragma unroll
-                    for (int dt = 0; dt < W::DT; ++dt)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xr, theirs + (uint32_t)(dt * 4 + q4) * NT * 16, 0, kAuxAgent);
-#pragma unroll
-                            for (int y = 0; y < 4; ++y) {
-                                const uint32_t ty = t[y];
-                                o[dt][4 * q4 + y] = fmaf(o[dt][4 * q4 + y], a1, __builtin_bit_cast(float, ty) * a2);
-                            }
-                        }
-                }
-            }
         }
     }
     float la, lb;
@@ -708,7 +567,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
         return;
     }
     const float inv = 1.f / (la + lb);
-    if (valid && write_out) {
+    if (valid) {
         uint16_t* op = p.out + (qrow0 + jrow) * p.o_stride + (int64_t)(h * G + grow) * D + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < W::DT; ++dt)
@@ -719,19 +578,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
                 w.y = pack16<F16>(o[dt][4 * q4 + 2] * inv, o[dt][4 * q4 + 3] * inv);
                 *reinterpret_cast<uint2*>(op + 32 * dt + 8 * q4) = w;
             }
-    }
-    if constexpr (!PERSIST) return;
-    __syncthreads();                                               // every wave has left the tile ring and the slot window
-    item = bcast[0];
-    }
-    if constexpr (PERSIST) {                                       // the last workgroup of the XCD to leave zeroes its counters
-        if (threadIdx.x == 0) {
-            const int n_wg_x = ((int)gridDim.x - vx + 7) >> 3;
-            if (__hip_atomic_fetch_add(ctr + 8 + vx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_wg_x - 1) {
-                __hip_atomic_store(ctr + vx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ctr + 8 + vx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
     }
 }
 
@@ -830,14 +676,6 @@ static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream
     (void)attr_done;
 #ifdef M355_DEV
     if constexpr (D == 128 && G == 4) {                            // phase stamps (tools/stamp_prefill.py)
-        if (g_prefill_stamps && p.ps_shift >= 0 && NW == 4 && NBUF == 4 && dev_env_int("M355_PREFILL_PERSIST", 1) && p.splits == 1 &&
-            (int64_t)grid.x > 2 * cu_count()) {
-            p.stamps = g_prefill_stamps;
-            p.ctr_slot = 255;
-            (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 4, 4, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((prefill_wg_kernel<D, G, 4, 4, true, true, false, true>), dim3(2 * cu_count()), block, lds + (kMaxSeg + 4) * 4, st, p);
-            return;
-        }
         if (g_prefill_stamps && p.ps_shift >= 0) {
             p.stamps = g_prefill_stamps;
             (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, NW, NBUF, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -846,29 +684,6 @@ static void launch_prefill_wg_cfg(PrefillParams p, int max_extend_len, hipStream
         }
     }
 #endif
-    // Persistent form (one workgroup per resident slot, row blocks taken from per-XCD counters): when the launch has more
-    // row blocks than the chip holds workgroups, so that slots would be vacated and refilled.
-    if constexpr (NW == 4 && NBUF == 4) {
-        const int n_wg = 2 * cu_count();
-        const int n_seg = (p.B * p.Hkv >> 3) + (p.B * p.Hkv & 7);
-        static const int persist_env = dev_env_int("M355_PREFILL_PERSIST", 1);
-        if (persist_env && D == 128 && p.splits == 1 && n_seg <= kMaxSeg && (int64_t)grid.x > n_wg && p.ps_shift >= 0) {   // (head_dim 64 holds 3 workgroups per CU in the other form, 2 in this one: slower)
-            static std::atomic<unsigned> ticket{0};
-            p.ctr_slot = (int32_t)(ticket.fetch_add(1, std::memory_order_relaxed) % kCtrSlots);
-            const size_t lds_p = lds + (kMaxSeg + 4) * 4;
-            const dim3 pgrid((unsigned)n_wg);
-            if (p.f16) {
-                static bool a16 = [] { (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 4, 4, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }();
-                (void)a16;
-                hipLaunchKernelGGL((prefill_wg_kernel<D, G, 4, 4, true, false, true, true>), pgrid, block, lds_p, st, p);
-            } else {
-                static bool a = [] { (void)hipFuncSetAttribute((const void*)prefill_wg_kernel<D, G, 4, 4, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }();
-                (void)a;
-                hipLaunchKernelGGL((prefill_wg_kernel<D, G, 4, 4, true, false, false, true>), pgrid, block, lds_p, st, p);
-            }
-            return;
-        }
-    }
     if (p.f16) {                                                   // (default geometry only: NW = 4, 4 tile buffers)
         if constexpr (NW == 4 && NBUF == 4) {
             static bool attr16 = [] {
@@ -926,17 +741,11 @@ extern "C" int m355dbg_set_prefill_stamp_buffer(void* dev_ptr) {   // dev build 
 }
 #endif
 
-// Exchange area of the persistent form's KV-split last round: 8 XCDs x kTailPieces pieces x 256 lanes x (D/2 O^T values + m, l, pad)
-static int64_t prefill_tail_bytes(int D) { return (int64_t)8 * kTailPieces * 256 * (D / 2 + 4) * (int64_t)sizeof(float); }
-
 extern "C" int64_t m355_prefill_workspace_bytes(int32_t T, int32_t Hq, int32_t D, int32_t max_seq_len_hint) {
     if (T <= 0 || Hq <= 0 || D <= 0 || max_seq_len_hint <= 0) return 0;
     if (prefill_mode() == 0) {                            // split-KV partials of the workgroup kernel (few rows, long KV)
         const int sp = prefill_splits(T, Hq, max_seq_len_hint);
-        if (sp > 1) return (int64_t)T * Hq * sp * (D + 4) * (int64_t)sizeof(float);
-        // more row blocks than resident workgroups: the persistent form may cut its last round's blocks (optional: without
-        // the area nothing is cut)
-        if ((D == 64 || D == 128) && (int64_t)T * Hq / 128 > 2 * cu_count()) return prefill_tail_bytes(D);
+        return sp > 1 ? (int64_t)T * Hq * sp * (D + 4) * (int64_t)sizeof(float) : 0;
     }
     return 0;
 }
@@ -973,17 +782,12 @@ extern "C" int m355_prefill_attn(const void* q, int64_t q_row_stride, const void
     p.ws = nullptr;
     p.splits = 1;
     p.f16 = f16 ? 1 : 0;
-    p.ctr_slot = 0;
-    p.tail_ws = nullptr;
     if (prefill_mode() == 0) {
         p.splits = prefill_splits(T, Hq, max_seq_len_hint);
         if (p.splits > 1) {
             const int64_t need = (int64_t)T * Hq * p.splits * (D + 4) * (int64_t)sizeof(float);
             if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return M355_ERR_WORKSPACE;
             p.ws = (float*)workspace;
-        } else if (workspace && workspace_bytes >= prefill_tail_bytes(D) && !((uintptr_t)workspace & 15) &&
-                   dev_env_int("M355_PREFILL_TAIL", 1)) {
-            p.tail_ws = (float*)workspace;
         }
     }
     if ((int64_t)B * Hkv * p.tiles_max > 0x7fffffffLL) return M355_ERR_INVALID_ARG;

@@ -25,8 +25,6 @@ struct PrefillParams {
     float* ws;                                        // split-KV partials [T*Hq rows][splits][D + 4: O, m, l, pad] (splits > 1)
     int32_t splits;                                   // KV splits per row block (blockIdx.y)
     int32_t f16;                                      // elements are IEEE half instead of bf16
-    int32_t ctr_slot;                                 // persistent form: this launch's group of work counters (g_prefill_ctr)
-    float* tail_ws;                                   // persistent form: exchange area of the KV-split blocks of the last round (nullptr: none are split)
 };
 
 template <int D>
@@ -52,10 +50,6 @@ template <int V> struct IntC { static constexpr int value = V; };
 constexpr int kPrio = M355_PREFILL_PRIO;          // s_setprio 1 around the MFMA clusters: 1 = QK^T only, 2 = PV too (each +1-2 % on cfg3, A/B on one box)
 constexpr float kLazy = 8.f;                          // log2 units
 constexpr int kSlotWin = 1024;                        // tokens whose pool slots are staged in LDS at a time
-constexpr int kMaxSeg = 1024;                         // persistent form: (request, kv head) pairs per XCD whose block counts fit the LDS table
-constexpr int kTailBlocks = 32, kTailPieces = 64;     // persistent form, per XCD: row blocks of the last round that are KV-split, pieces they make
-constexpr int kCtrSlots = 256, kCtrWords = 16 + 8 * kTailBlocks;   // a group of counters per launch in flight (handed out round-robin):
-                                                      // 8 + 8 work counters, then one arrival counter per split block
 
 
 // 64 rows per wave (prefill_wg2.hip); false when the head shape has no such kernel
