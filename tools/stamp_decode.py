@@ -50,16 +50,11 @@ setter = lib.m355dbg_set_stream_stamp_buffer
 setter.argtypes = [ctypes.c_void_p]
 assert setter(stamps.data_ptr()) == 0
 plan = ops.decode_plan(pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, Hkv, D, sum(lens), pool_row_stride=ops.pool_pitch(*kv.get_kv_cache(0))) if STREAM else None
-ws = torch.empty(ops.decode_workspace_bytes(B, Hq, D, max_len, chunk), dtype=torch.uint8, device=dev)
 
 
 def run(layer):
     kp, vp = kv.get_kv_cache(layer)
-    if STREAM:
-        ops.decode_attn_planned(q, kp, vp, plan, Hq)
-        return
-    ops.decode_attn(q, kp, vp, pm.page_table, batch.page_table_ids, batch.seq_lens, ps, Hq, max_len,
-                    chunk_tokens=chunk, workspace=ws)
+    ops.decode_attn_planned(q, kp, vp, plan, Hq)
 
 
 for l in range(L):
