@@ -252,8 +252,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void prefill_wg_kernel(co
     int tb, bh;
     if ((int)blockIdx.x < mapped) {
         int item = blockIdx.x >> 3;
-        tb = p.tiles_max - 1 - item % p.tiles_max;
-        bh = (item / p.tiles_max) * 8 + (blockIdx.x & 7);
+        // ... except each pair's EARLIEST row block (the shortest walk): those come after all the others, so the launch's
+        // last, partly filled round is made of the shortest blocks (cfg3 144.0 -> 142.3 us, twice the groups 277 -> 270;
+        // holding back two or four per pair is no better: profiles/r03_prefill_order_ab.txt)
+        const int hold = p.tiles_max > 1 ? 1 : 0, lead = p.tiles_max - hold;
+        const int n_lead = (n_bh >> 3) * lead;
+        if (item < n_lead) { tb = p.tiles_max - 1 - item % lead; bh = (item / lead) * 8 + (blockIdx.x & 7); }
+        else { tb = 0; bh = (item - n_lead) * 8 + (blockIdx.x & 7); }
     } else {
         const int item = blockIdx.x - mapped;
         tb = p.tiles_max - 1 - item % p.tiles_max;
