@@ -26,13 +26,17 @@ from mi355_attn import _lib, ops  # noqa: E402
 
 dev = "cuda:0"
 Hq, Hkv, D, ps, L = 32, 8, 64, 16, 4
-chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+chunk = 256
 random.seed(0)
 lens = [random.randint(64, 2048) + 1 for _ in range(64)]
+if len(sys.argv) > 1:                                  # usage: stamp_decode.py [Hq,Hkv,D fixed_len batch]
+    Hq, Hkv, D = (int(x) for x in sys.argv[1].split(","))
+    lens = [int(sys.argv[2])] * int(sys.argv[3])
+os.environ.setdefault("M355_DECODE_SHARE", "0")        # the range kernel is what this tool stamps
 B = len(lens)
 pages = sum(-(-l // ps) for l in lens) + 8
 kv = m.KVCache(pages * ps, ps, Hkv, D, torch.bfloat16, L, dev)
-pm = m.PageManager(ps, B, 4096, dev)
+pm = m.PageManager(ps, B, max(4096, max(lens) + 64), dev)
 kv._free = deque(torch.randperm(pages, generator=torch.Generator().manual_seed(0)).tolist())
 kv._store.copy_(torch.randn(kv._store.shape, device=dev).to(torch.bfloat16))
 reqs = [m.Req(i, list(range(l))) for i, l in enumerate(lens)]
@@ -65,7 +69,7 @@ torch.cuda.synchronize()
 run(0)
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.int64)
-live = s[:, 5] > 0
+live = (s[:, 5] > 0) & (s[:, 1] > 0) & (s[:, 4] > 0)      # waves that had a range (the others leave at the record)
 dead = (s[:, 0] > 0) & ~live
 t0 = s[s[:, 0] > 0, 0].min()
 print(f"chunk {chunk}: blocks {nblocks}, live {live.sum()}, dead {dead.sum()}")
@@ -90,14 +94,14 @@ if STREAM:
     nwh = 256 * 8 // Hkv
     loop = (a[:, 4] - a[:, 3]) * 0.01
     life = (a[:, 5] - a[:, 0]) * 0.01
-    w = np.arange(nblocks) // Hkv
+    w = (np.arange(nblocks) // Hkv)[live]
     npieces = np.array([np.searchsorted(cum, min((x + 1) * R, total), side="left") - np.searchsorted(cum, x * R, side="right") + 1 for x in w])
     print(f"R={R} ranges={nr} total={total}")
     for k in sorted(set(npieces)):
         sel = npieces == k
         print(f"pieces={k}: waves {sel.sum():5d}  loop median {np.median(loop[sel]):.2f}  p95 {np.percentile(loop[sel],95):.2f}")
     for x in range(8):
-        sel = (np.arange(nblocks) % 8) == x
+        sel = ((np.arange(nblocks) % 8) == x)[live]
         print(f"blockIdx%8={x}: loop median {np.median(loop[sel]):.2f} p95 {np.percentile(loop[sel],95):.2f} life median {np.median(life[sel]):.2f}")
     # last waves of the stream have a short range
     print("loop time of the 16 slowest waves:", np.sort(loop)[-16:].round(1), "their w:", w[np.argsort(loop)[-16:]])
